@@ -1,0 +1,190 @@
+/* slam_pf.h — C ABI of the MI355X (gfx950) particle-filter hot path.
+ *
+ * Drop-in seam for Gabrieleenx/SLAM's Slam_3d_particle.cpp ("S3P"). The reference has no FFI:
+ * main() calls particle_map() directly (S3P:1106-1108) and everything travels through globals.
+ * This header is the seam INSIDE particle_map() / build_local_map(): the caller (the host
+ * driver: snapshot under its mutex, motion model + noise, add_points policy, correction
+ * feedback) keeps what S3P:833-855, 911-914, 941-953, 956-959 do and hands the loops
+ * S3P:859-908, 920-937, 757-821 and 628-704 to the GPU, in the reference's own per-step order
+ *     measure (uses the poses of the previous step)  ->  predict  ->  weights  ->  resample
+ * plus update_map once per depth frame. INTEGRATION.md shows the edit to the reference.
+ *
+ * Conventions: every function returns PF_OK (0) or a negative PF_ERR_*; pf_last_error() gives
+ * the text. No exceptions cross the boundary, no torch types, plain pointers and sizes. Host
+ * pointers are the caller's and may be reused on return. One caller thread per handle (the
+ * reference calls particle_map() from main() only). Work is ordered on the handle's own HIP
+ * stream; functions that fill host memory return after the data has arrived, the others are
+ * asynchronous on that stream. The library is HIP-only: there is no CPU fallback, and
+ * pf_create fails when no gfx950 device is usable.
+ */
+#ifndef SLAM_PF_H
+#define SLAM_PF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_OK            0
+#define PF_ERR_ARG      -1   /* bad argument / size beyond a configured capacity */
+#define PF_ERR_HIP      -2   /* a HIP runtime call failed */
+#define PF_ERR_STATE    -3   /* call order violated (e.g. weights before measure) */
+#define PF_ERR_NOMEM    -4
+#define PF_ERR_NODEVICE -5
+
+#define PF_MAP_SHARED        0   /* one uint8 grid read by every particle (S3P:64 style)   */
+#define PF_MAP_PER_PARTICLE  1   /* one uint8 slab per particle (S3P:52, FastSLAM style)   */
+
+#define PF_ORDER_AUTO   0   /* exact for n_particles_global <= 2048, else fast             */
+#define PF_ORDER_EXACT  1   /* weight sum and CDF added in the reference's sequential order */
+#define PF_ORDER_FAST   2   /* fixed-shape parallel sum/scan; ambiguous draws are counted   */
+
+#define PF_GRID_SHARED  0   /* pf_update_map target: the shared uint8 grid                 */
+#define PF_GRID_LOCAL   1   /* pf_update_map target: the int8 local map (S3P:65)           */
+
+/* kernel ids for pf_kernel_time */
+#define PF_K_MEASURE   0
+#define PF_K_WEIGHTS   1
+#define PF_K_RESAMPLE  2
+#define PF_K_UPDATE    3
+#define PF_K_COUNT     4
+
+typedef struct pf_handle pf_handle;
+
+/* Replaces the compile-time constants and globals of S3P:23-69. */
+typedef struct pf_config {
+    int32_t struct_size;          /* = sizeof(pf_config) */
+    int32_t device;               /* HIP device ordinal */
+    int32_t n_particles;          /* particles held by THIS handle (S3P:68: 50) */
+    int32_t n_particles_global;   /* over all handles/ranks; == n_particles on one GPU */
+    int32_t particle_offset;      /* global slot number of local slot 0 */
+    int32_t map_mode;             /* PF_MAP_* */
+    int32_t grid_x, grid_y, grid_z;   /* S3P:40-42: 300,300,80; flat = x*gy*gz + y*gz + z */
+    int32_t local_x, local_y, local_z; /* S3P:30-32: 200,200,80; 0 = no local map */
+    int32_t max_beams;            /* capacity of pf_set_beams */
+    int32_t max_points;           /* capacity of pf_set_scan (points and rays) */
+    int32_t occ_threshold;        /* S3P:886: 20 */
+    int32_t map_lo, map_hi;       /* S3P:896-901: 0, 100 */
+    int32_t map_prior;            /* S3P:74: 50 */
+    int32_t order_mode;           /* PF_ORDER_* */
+    double  resolution;           /* S3P:23: 0.05 */
+} pf_config;
+
+/* Replaces the literals of S3P:637, 650-655, 695-700. */
+typedef struct pf_update_params {
+    int32_t hit_inc, hit_clamp;     /* +10, 50 (local int8)  */
+    int32_t miss_inc, miss_clamp;   /* -3, -50 */
+    double  max_range;              /* 3.0 m: endpoints farther than this are not hits */
+} pf_update_params;
+
+/* Fills *cfg with the reference's values (S3P:23-69), one GPU, per-particle maps. */
+int pf_default_config(pf_config* cfg);
+
+/* Replaces `new map_particles[50]` + initilize_particles_map() (S3P:69-77, S3P:1087): allocates
+ * all device state; poses start at S3P:47-50 (7.5,7.5,1.5,0), weights at 1/n_particles_global,
+ * maps at map_prior. */
+int pf_create(const pf_config* cfg, pf_handle** out);
+/* Replaces the delete[]s of S3P:1065-1068. */
+void pf_destroy(pf_handle* h);
+/* Text of the last error on this handle (h == NULL: of the last failed pf_create). */
+const char* pf_last_error(const pf_handle* h);
+
+/* ---- particle state ------------------------------------------------------------------ */
+
+/* Replaces the result of S3P:911-914 (the caller keeps the motion model and its RNG): uploads
+ * the local shard's poses. The library computes cos/sin(yaw) with the host libm (as S3P:860
+ * does through rot_matrix) and pos/resolution (S3P:862-864) on the host. */
+int pf_predict(pf_handle* h, const double* x, const double* y, const double* z, const double* yaw);
+int pf_get_poses(pf_handle* h, double* x, double* y, double* z, double* yaw);
+/* weight vector of ALL n_particles_global particles (S3P:51; every rank holds the whole vector) */
+int pf_set_weights(pf_handle* h, const double* w_global);
+int pf_get_weights(pf_handle* h, double* w_global, float* logw_global /* may be NULL */);
+
+/* maps: PER_PARTICLE: slab `i` of the local shard; SHARED: i is ignored. Replaces the reads at
+ * S3P:1031-1051 and test set-up. */
+int pf_fill_maps(pf_handle* h, int value);
+int pf_write_map(pf_handle* h, int32_t i, const uint8_t* src);
+int pf_broadcast_map(pf_handle* h, const uint8_t* src);   /* every local particle := src */
+int pf_read_map(pf_handle* h, int32_t i, uint8_t* dst);
+
+/* ---- measurement: S3P:859-908 ---------------------------------------------------------- */
+
+/* The step's beam list = the caller's snapshot (S3P:833-846, 868-877): non-zero local voxels
+ * in ascending flat order as offsets from the local origin, with their int8 value. */
+int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32_t* bz,
+                 const int8_t* bv, int64_t n_beams);
+/* K1 (+K2 when add_points and PER_PARTICLE): per local particle sum_match / num_match. */
+int pf_measure(pf_handle* h, int add_points);
+int pf_get_scores(pf_handle* h, int32_t* sum_match, int32_t* num_match);
+/* device pointer to the local scores, int32 [n_particles][2] = (sum, count): what the caller
+ * all-gathers across ranks (RCCL) before pf_weights. */
+void* pf_scores_device(pf_handle* h);
+/* parity object "voxel indices": flat index (or -1) of every beam for local particle i. */
+int pf_voxel_indices(pf_handle* h, int32_t i, int32_t* flat_out);
+
+/* ---- weights: S3P:920-937 ---------------------------------------------------------------- */
+
+/* scores_global_dev: device pointer to int32 [n_particles_global][2] gathered over the ranks
+ * in rank order, or NULL on one GPU (the local scores are used). */
+int pf_weights(pf_handle* h, const void* scores_global_dev);
+
+/* ---- resample: S3P:757-821 --------------------------------------------------------------- */
+
+/* u_global: n_particles_global thresholds in draw order (reference parity: the mt19937
+ * uniforms of S3P:770-773; systematic resampling: (u0+i)/N), or NULL to reuse the resident
+ * ones. poses_global_dev: device pointer to the ranks' pose blocks gathered in rank order
+ * (each block = what pf_poses_device points to), or NULL on one GPU.
+ * slot_anc_out[n_particles_global] (may be NULL) = S3P's resample_index_org; *best_out =
+ * S3P's index_high_weight; *nohit_out = draws that matched no interval (kept own index);
+ * *ambiguous_out = draws closer to a CDF boundary than the FAST-order error bound (they are
+ * re-searched on the sequential-order CDF before use; 0 in EXACT order). */
+int pf_resample(pf_handle* h, const double* u_global, const void* poses_global_dev,
+                int32_t* slot_anc_out, int32_t* best_out, int64_t* nohit_out,
+                int64_t* ambiguous_out);
+/* device pointer to the local pose block, double [9][n_particles]:
+ * x, y, z, yaw, cos, sin, x/res, y/res, z/res. */
+void* pf_poses_device(pf_handle* h);
+
+/* ---- map update: S3P:628-704 -------------------------------------------------------------- */
+
+/* points: n_points rows of sensor-frame xyz (S3P:126 cloudpoints); ray_idx: n_rays rows to cast
+ * to (S3P:668-672: 2400 host-drawn indices; north-star: every beam). */
+int pf_set_scan(pf_handle* h, const double* points, int64_t n_points,
+                const int32_t* ray_idx, int64_t n_rays);
+/* K5: hits then ray march on `target`. pos: sensor position in the grid frame (metres),
+ * zyx: angles (S3P:628-631). */
+int pf_update_map(pf_handle* h, int target, const pf_update_params* p,
+                  const double pos[3], const double zyx[3]);
+int pf_write_local_map(pf_handle* h, const int8_t* src);
+int pf_read_local_map(pf_handle* h, int8_t* dst);
+int pf_reset_local_map(pf_handle* h);                    /* S3P:750-754 */
+
+/* ---- plumbing ------------------------------------------------------------------------------ */
+void* pf_stream(pf_handle* h);                           /* the handle's hipStream_t */
+int pf_synchronize(pf_handle* h);
+/* HIP-event timing of the kernels, per class; off by default. */
+int pf_profile(pf_handle* h, int enable);
+int pf_kernel_time(pf_handle* h, int kernel_id, double* total_ms, int64_t* launches);
+
+/* ---- host-driver helpers (no GPU): the caller-side lines of the reference ------------------- */
+
+/* S3P:868-877: beams of an int8 local map, ascending; returns the count (or -needed if > cap). */
+int64_t pfh_snapshot_beams(const int8_t* local, int32_t lgx, int32_t lgy, int32_t lgz,
+                           int32_t ox, int32_t oy, int32_t oz,
+                           int32_t* bx, int32_t* by, int32_t* bz, int8_t* bv, int64_t cap);
+/* S3P:911-914 with the noise given (4 floats per particle: pos_d, pos_d, rot_d, rot_d). */
+void pfh_predict(int64_t n, double* x, double* y, double* z, double* yaw,
+                 double dlx, double dly, double dlz, double dyaw, const float* noise);
+/* the libstdc++ draws of S3P:852-855 / S3P:768-773 from one seed */
+void pfh_draw_noise(uint32_t seed, int64_t n, float sigma_pos, float sigma_rot, float* noise);
+void pfh_draw_uniform(uint32_t seed, int64_t n, double* u);
+/* S3P:941-953: returns the new add_points and updates last[4] when the pose moved > 0.4. */
+int pfh_add_points_policy(const double pose[4], double last[4], double threshold);
+/* S3P:805-812 on the caller's own per-particle records. */
+void pfh_permute(int64_t n, const int32_t* slot_anc, void* records, size_t width);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

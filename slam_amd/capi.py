@@ -1,0 +1,311 @@
+"""ctypes binding of include/slam_pf.h (slam_amd/csrc/libslam_pf.so).
+
+Plumbing only: the product is the shared library. Loading fails loudly when the library has
+not been built; there is no Python or CPU substitute for any entry point.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libslam_pf.so")
+
+PF_OK = 0
+PF_MAP_SHARED, PF_MAP_PER_PARTICLE = 0, 1
+PF_ORDER_AUTO, PF_ORDER_EXACT, PF_ORDER_FAST = 0, 1, 2
+PF_GRID_SHARED, PF_GRID_LOCAL = 0, 1
+PF_K_MEASURE, PF_K_WEIGHTS, PF_K_RESAMPLE, PF_K_UPDATE = 0, 1, 2, 3
+
+# every symbol include/slam_pf.h declares (tests check the library exports exactly these)
+SYMBOLS = (
+    "pf_default_config pf_create pf_destroy pf_last_error pf_predict pf_get_poses pf_set_weights "
+    "pf_get_weights pf_fill_maps pf_write_map pf_broadcast_map pf_read_map pf_set_beams "
+    "pf_measure pf_get_scores pf_scores_device pf_voxel_indices pf_weights pf_resample "
+    "pf_poses_device pf_set_scan pf_update_map pf_write_local_map pf_read_local_map "
+    "pf_reset_local_map pf_stream pf_synchronize pf_profile pf_kernel_time "
+    "pfh_snapshot_beams pfh_predict pfh_draw_noise pfh_draw_uniform pfh_add_points_policy "
+    "pfh_permute").split()
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32),
+                ("n_particles", C.c_int32), ("n_particles_global", C.c_int32),
+                ("particle_offset", C.c_int32), ("map_mode", C.c_int32),
+                ("grid_x", C.c_int32), ("grid_y", C.c_int32), ("grid_z", C.c_int32),
+                ("local_x", C.c_int32), ("local_y", C.c_int32), ("local_z", C.c_int32),
+                ("max_beams", C.c_int32), ("max_points", C.c_int32),
+                ("occ_threshold", C.c_int32), ("map_lo", C.c_int32), ("map_hi", C.c_int32),
+                ("map_prior", C.c_int32), ("order_mode", C.c_int32),
+                ("resolution", C.c_double)]
+
+
+class UpdateParams(C.Structure):
+    _fields_ = [("hit_inc", C.c_int32), ("hit_clamp", C.c_int32),
+                ("miss_inc", C.c_int32), ("miss_clamp", C.c_int32),
+                ("max_range", C.c_double)]
+
+
+class PfError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PfError(f"{LIB_PATH} is missing: build it with `make -C slam_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.pf_last_error.restype = C.c_char_p
+        L.pf_last_error.argtypes = [C.c_void_p]
+        for name in ("pf_scores_device", "pf_poses_device", "pf_stream"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.pfh_snapshot_beams.restype = C.c_int64
+        L.pf_destroy.restype = None
+        L.pf_destroy.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def default_config(**kw):
+    cfg = Config()
+    rc = lib().pf_default_config(C.byref(cfg))
+    assert rc == PF_OK
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    if "n_particles" in kw and "n_particles_global" not in kw:
+        cfg.n_particles_global = cfg.n_particles
+    return cfg
+
+
+class Handle:
+    """One pf_handle: one GPU's shard of the filter. Methods map 1:1 to the C ABI."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        rc = lib().pf_create(C.byref(cfg), C.byref(self._h))
+        if rc != PF_OK:
+            raise PfError(f"pf_create -> {rc}: {lib().pf_last_error(None).decode()}")
+        self.P = cfg.n_particles
+        self.Pg = cfg.n_particles_global
+        self.elements = cfg.grid_x * cfg.grid_y * cfg.grid_z
+        self.local_elements = cfg.local_x * cfg.local_y * cfg.local_z
+
+    def close(self):
+        if self._h:
+            lib().pf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != PF_OK:
+            raise PfError(f"{what} -> {rc}: {lib().pf_last_error(self._h).decode()}")
+
+    # --- state ---
+    def predict(self, x, y, z, yaw):
+        x, y, z, yaw = (_c(a, np.float64) for a in (x, y, z, yaw))
+        assert len(x) == len(y) == len(z) == len(yaw) == self.P
+        self._ck(lib().pf_predict(self._h, _p(x), _p(y), _p(z), _p(yaw)), "pf_predict")
+
+    def get_poses(self):
+        out = [np.empty(self.P, np.float64) for _ in range(4)]
+        self._ck(lib().pf_get_poses(self._h, *[_p(a) for a in out]), "pf_get_poses")
+        return out
+
+    def set_weights(self, w):
+        w = _c(w, np.float64)
+        assert len(w) == self.Pg
+        self._ck(lib().pf_set_weights(self._h, _p(w)), "pf_set_weights")
+
+    def get_weights(self):
+        w = np.empty(self.Pg, np.float64)
+        lw = np.empty(self.Pg, np.float32)
+        self._ck(lib().pf_get_weights(self._h, _p(w), _p(lw)), "pf_get_weights")
+        return w, lw
+
+    def fill_maps(self, value):
+        self._ck(lib().pf_fill_maps(self._h, int(value)), "pf_fill_maps")
+
+    def write_map(self, i, src):
+        src = _c(src, np.uint8).reshape(-1)
+        assert src.size == self.elements
+        self._ck(lib().pf_write_map(self._h, int(i), _p(src)), "pf_write_map")
+
+    def broadcast_map(self, src):
+        src = _c(src, np.uint8).reshape(-1)
+        assert src.size == self.elements
+        self._ck(lib().pf_broadcast_map(self._h, _p(src)), "pf_broadcast_map")
+
+    def read_map(self, i=0):
+        dst = np.empty(self.elements, np.uint8)
+        self._ck(lib().pf_read_map(self._h, int(i), _p(dst)), "pf_read_map")
+        return dst
+
+    # --- measurement ---
+    def set_beams(self, bx, by, bz, bv):
+        bx, by, bz = (_c(a, np.int32) for a in (bx, by, bz))
+        bv = _c(bv, np.int8)
+        assert len(bx) == len(by) == len(bz) == len(bv)
+        self._ck(lib().pf_set_beams(self._h, _p(bx), _p(by), _p(bz), _p(bv), C.c_int64(len(bx))),
+                 "pf_set_beams")
+        self.M = len(bx)
+
+    def measure(self, add_points):
+        self._ck(lib().pf_measure(self._h, int(add_points)), "pf_measure")
+
+    def get_scores(self):
+        s = np.empty(self.P, np.int32); c = np.empty(self.P, np.int32)
+        self._ck(lib().pf_get_scores(self._h, _p(s), _p(c)), "pf_get_scores")
+        return s, c
+
+    def scores_device(self):
+        return lib().pf_scores_device(self._h)
+
+    def poses_device(self):
+        return lib().pf_poses_device(self._h)
+
+    def _device_tensor(self, ptr, shape, typestr):
+        import torch
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False),
+                                      "version": 2}
+        return torch.as_tensor(v, device=f"cuda:{self.cfg.device}")
+
+    def scores_tensor(self):
+        """torch view (no copy) of the local scores, int32 [n_particles, 2], for the all-gather."""
+        return self._device_tensor(self.scores_device(), (self.P, 2), "<i4")
+
+    def poses_tensor(self):
+        """torch view (no copy) of the local pose block, float64 [9, n_particles]."""
+        return self._device_tensor(self.poses_device(), (9, self.P), "<f8")
+
+    def voxel_indices(self, i):
+        out = np.empty(self.M, np.int32)
+        self._ck(lib().pf_voxel_indices(self._h, int(i), _p(out)), "pf_voxel_indices")
+        return out
+
+    # --- weights / resample ---
+    def weights(self, scores_global_dev=None):
+        self._ck(lib().pf_weights(self._h, C.c_void_p(scores_global_dev)), "pf_weights")
+
+    def resample(self, u=None, poses_global_dev=None, want_slots=True):
+        if u is not None:
+            u = _c(u, np.float64)
+            assert len(u) == self.Pg
+        slots = np.empty(self.Pg, np.int32) if want_slots else None
+        best = C.c_int32(-1); nohit = C.c_int64(0); amb = C.c_int64(0)
+        self._ck(lib().pf_resample(self._h, _p(u), C.c_void_p(poses_global_dev), _p(slots),
+                                   C.byref(best), C.byref(nohit), C.byref(amb)), "pf_resample")
+        return slots, best.value, nohit.value, amb.value
+
+    # --- map update ---
+    def set_scan(self, points, ray_idx):
+        points = _c(points, np.float64).reshape(-1, 3)
+        ray_idx = _c(ray_idx, np.int32)
+        self._ck(lib().pf_set_scan(self._h, _p(points), C.c_int64(len(points)), _p(ray_idx),
+                                   C.c_int64(len(ray_idx))), "pf_set_scan")
+
+    def update_map(self, target, params, pos, zyx):
+        pos = _c(pos, np.float64); zyx = _c(zyx, np.float64)
+        self._ck(lib().pf_update_map(self._h, int(target), C.byref(params), _p(pos), _p(zyx)),
+                 "pf_update_map")
+
+    def write_local_map(self, src):
+        src = _c(src, np.int8).reshape(-1)
+        assert src.size == self.local_elements
+        self._ck(lib().pf_write_local_map(self._h, _p(src)), "pf_write_local_map")
+
+    def read_local_map(self):
+        dst = np.empty(self.local_elements, np.int8)
+        self._ck(lib().pf_read_local_map(self._h, _p(dst)), "pf_read_local_map")
+        return dst
+
+    def reset_local_map(self):
+        self._ck(lib().pf_reset_local_map(self._h), "pf_reset_local_map")
+
+    # --- plumbing ---
+    def stream(self):
+        return lib().pf_stream(self._h)
+
+    def synchronize(self):
+        self._ck(lib().pf_synchronize(self._h), "pf_synchronize")
+
+    def profile(self, on):
+        self._ck(lib().pf_profile(self._h, int(on)), "pf_profile")
+
+    def kernel_time(self, kid):
+        ms = C.c_double(0); n = C.c_int64(0)
+        self._ck(lib().pf_kernel_time(self._h, int(kid), C.byref(ms), C.byref(n)), "pf_kernel_time")
+        return ms.value, n.value
+
+
+# ---- host-driver helpers (no GPU) ----------------------------------------------------------
+
+def snapshot_beams(local, origin):
+    local = _c(local, np.int8)
+    lgx, lgy, lgz = local.shape
+    cap = int(np.count_nonzero(local))
+    bx = np.empty(cap, np.int32); by = np.empty(cap, np.int32); bz = np.empty(cap, np.int32)
+    bv = np.empty(cap, np.int8)
+    n = lib().pfh_snapshot_beams(_p(local), lgx, lgy, lgz, int(origin[0]), int(origin[1]),
+                                 int(origin[2]), _p(bx), _p(by), _p(bz), _p(bv), C.c_int64(cap))
+    assert n == cap, (n, cap)
+    return bx, by, bz, bv
+
+
+def host_predict(x, y, z, yaw, dl, dyaw, noise):
+    noise = _c(noise, np.float32)
+    for a in (x, y, z, yaw):
+        assert a.dtype == np.float64 and a.flags.c_contiguous
+    lib().pfh_predict(C.c_int64(len(x)), _p(x), _p(y), _p(z), _p(yaw), C.c_double(dl[0]),
+                      C.c_double(dl[1]), C.c_double(dl[2]), C.c_double(dyaw), _p(noise))
+
+
+def draw_noise(seed, n, sigma_pos=0.03, sigma_rot=0.02):
+    out = np.empty((n, 4), np.float32)
+    lib().pfh_draw_noise(C.c_uint32(seed), C.c_int64(n), C.c_float(sigma_pos), C.c_float(sigma_rot),
+                         _p(out))
+    return out
+
+
+def draw_uniform(seed, n):
+    out = np.empty(n, np.float64)
+    lib().pfh_draw_uniform(C.c_uint32(seed), C.c_int64(n), _p(out))
+    return out
+
+
+def add_points_policy(pose, last, threshold=0.4):
+    pose = _c(pose, np.float64)
+    assert last.dtype == np.float64 and last.flags.c_contiguous and len(last) == 4
+    return int(lib().pfh_add_points_policy(_p(pose), _p(last), C.c_double(threshold)))
+
+
+def permute(slot_anc, records):
+    assert records.flags.c_contiguous
+    slot_anc = _c(slot_anc, np.int32)
+    lib().pfh_permute(C.c_int64(len(slot_anc)), _p(slot_anc), _p(records),
+                      C.c_size_t(records.strides[0]))

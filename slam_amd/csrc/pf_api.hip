@@ -1,0 +1,648 @@
+// C ABI of include/slam_pf.h: handle, device memory, stream ordering, argument checks.
+// HIP-only by design: there is no CPU path in this library.
+#include "../../include/slam_pf.h"
+#include "pf_kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+struct EventPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct pf_handle {
+    pf_config cfg;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // sizes
+    int P = 0, Pg = 0, offset = 0;
+    long long elements = 0;            // cells per grid
+    unsigned long long slab = 0;       // bytes between per-particle slabs (0 in shared mode)
+    long long local_elements = 0;
+    // device state
+    double* pose = nullptr;            // [9][P]
+    double* w = nullptr;               // [Pg]
+    float* logw = nullptr;             // [Pg]
+    double* cdf = nullptr;             // [Pg+1]
+    double* scratch = nullptr;         // [Pg+1]
+    double* u = nullptr;               // [Pg]
+    uint8_t* maps = nullptr;           // shared grid or P slabs
+    int8_t* local = nullptr;           // local int8 map
+    PfBeam* beams = nullptr;           // [max_beams]
+    int2* partial = nullptr;           // [max_chunks][P]
+    int2* scores = nullptr;            // [P]
+    int32_t* draw = nullptr;           // [Pg]
+    int32_t* first = nullptr;          // [Pg]
+    int32_t* dup_anc = nullptr;        // [Pg]
+    int32_t* free_slot = nullptr;      // [Pg]
+    int32_t* slot_anc = nullptr;       // [Pg]
+    int32_t* best = nullptr;           // [1]
+    unsigned long long* counters = nullptr;   // [2]
+    int32_t* vox = nullptr;            // [max_beams]
+    double* points = nullptr;          // [max_points][3]
+    double* wpts = nullptr;            // [max_points][3]
+    int32_t* ray_idx = nullptr;        // [max_points]
+    // host staging
+    std::vector<double> h_pose;
+    std::vector<PfBeam> h_beams;
+    int max_chunks = 1;
+    int M = 0;                         // resident beams
+    int n_points = 0, n_rays = 0;
+    bool measured = false, weighted = false, have_u = false;
+    bool exact = true;
+    // profiling
+    bool profile = false;
+    std::vector<EventPair> ev[PF_K_COUNT];
+    std::vector<EventPair> ev_pool;
+};
+
+namespace {
+
+int fail(pf_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                    \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(h, PF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+#define NEED(h, cond, msg)                                                                  \
+    do { if (!(cond)) return fail(h, PF_ERR_ARG, "%s: %s", __func__, msg); } while (0)
+
+template <typename T>
+hipError_t dalloc(T** p, size_t n) {
+    return hipMalloc((void**)p, (n ? n : 1) * sizeof(T));
+}
+
+unsigned long long round_up(unsigned long long v, unsigned long long a) { return (v + a - 1) / a * a; }
+
+PfGridParams grid_params(const pf_handle* h) {
+    PfGridParams gp;
+    gp.gyz = (double)h->cfg.grid_y * (double)h->cfg.grid_z;
+    gp.gzd = (double)h->cfg.grid_z;
+    gp.elements = (double)h->elements;
+    gp.occ_threshold = h->cfg.occ_threshold;
+    gp.lo = h->cfg.map_lo;
+    gp.hi = h->cfg.map_hi;
+    return gp;
+}
+
+struct Timed {
+    pf_handle* h; int id; EventPair ep{}; bool on = false;
+    Timed(pf_handle* h_, int id_) : h(h_), id(id_) {
+        if (!h->profile) return;
+        if (!h->ev_pool.empty()) { ep = h->ev_pool.back(); h->ev_pool.pop_back(); }
+        else if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) return;
+        on = hipEventRecord(ep.a, h->stream) == hipSuccess;
+    }
+    ~Timed() {
+        if (!on) return;
+        (void)hipEventRecord(ep.b, h->stream);
+        h->ev[id].push_back(ep);
+    }
+};
+
+void upload_pose_rows(pf_handle* h, const double* x, const double* y, const double* z,
+                      const double* yaw) {
+    const int P = h->P;
+    double* hp = h->h_pose.data();
+    const double res = h->cfg.resolution;
+    for (int i = 0; i < P; ++i) {
+        hp[0 * (size_t)P + i] = x[i];
+        hp[1 * (size_t)P + i] = y[i];
+        hp[2 * (size_t)P + i] = z[i];
+        hp[3 * (size_t)P + i] = yaw[i];
+        hp[4 * (size_t)P + i] = cos(yaw[i]);          // S3P:860 via rot_matrix (host libm)
+        hp[5 * (size_t)P + i] = sin(yaw[i]);
+        hp[6 * (size_t)P + i] = x[i] * 1 / res;       // S3P:862-864: a division
+        hp[7 * (size_t)P + i] = y[i] * 1 / res;
+        hp[8 * (size_t)P + i] = z[i] * 1 / res;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pf_default_config(pf_config* c) {
+    if (!c) return PF_ERR_ARG;
+    memset(c, 0, sizeof *c);
+    c->struct_size = (int32_t)sizeof(pf_config);
+    c->device = 0;
+    c->n_particles = 50; c->n_particles_global = 50; c->particle_offset = 0;
+    c->map_mode = PF_MAP_PER_PARTICLE;
+    c->grid_x = 300; c->grid_y = 300; c->grid_z = 80;
+    c->local_x = 200; c->local_y = 200; c->local_z = 80;
+    c->max_beams = 1 << 17; c->max_points = 19200;
+    c->occ_threshold = 20; c->map_lo = 0; c->map_hi = 100; c->map_prior = 50;
+    c->order_mode = PF_ORDER_AUTO;
+    c->resolution = 0.05;
+    return PF_OK;
+}
+
+const char* pf_last_error(const pf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+void pf_destroy(pf_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams,
+                    h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
+                    h->slot_anc, h->best, h->counters, h->vox, h->points, h->wpts, h->ray_idx};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& v : h->ev) for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int pf_create(const pf_config* cfg, pf_handle** out) {
+    if (!cfg || !out) return fail(nullptr, PF_ERR_ARG, "pf_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(pf_config))
+        return fail(nullptr, PF_ERR_ARG, "pf_create: struct_size %d != %zu", cfg->struct_size,
+                    sizeof(pf_config));
+    const pf_config& c = *cfg;
+    if (c.n_particles < 1 || c.n_particles_global < c.n_particles || c.particle_offset < 0 ||
+        (long long)c.particle_offset + c.n_particles > c.n_particles_global)
+        return fail(nullptr, PF_ERR_ARG, "pf_create: particle counts/offset inconsistent");
+    if (c.n_particles_global != c.n_particles && c.n_particles_global % c.n_particles != 0)
+        return fail(nullptr, PF_ERR_ARG, "pf_create: shards must be equal (n_global %% n_local != 0)");
+    if (c.grid_x < 1 || c.grid_y < 1 || c.grid_z < 1 ||
+        (long long)c.grid_x * c.grid_y * c.grid_z >= 2147483647LL ||
+        (long long)c.grid_y * c.grid_z >= (1LL << 26))
+        return fail(nullptr, PF_ERR_ARG, "pf_create: grid dims out of range");
+    if (c.local_x < 0 || c.local_y < 0 || c.local_z < 0 ||
+        (long long)c.local_x * c.local_y * c.local_z >= 2147483647LL)
+        return fail(nullptr, PF_ERR_ARG, "pf_create: local dims out of range");
+    if (c.map_mode != PF_MAP_SHARED && c.map_mode != PF_MAP_PER_PARTICLE)
+        return fail(nullptr, PF_ERR_ARG, "pf_create: map_mode");
+    if (c.map_mode == PF_MAP_PER_PARTICLE && c.n_particles_global != c.n_particles)
+        return fail(nullptr, PF_ERR_ARG,
+                    "pf_create: per-particle maps are single-handle for now (map migration "
+                    "between ranks is not implemented)");
+    if (!(c.resolution > 0.0) || c.max_beams < 1 || c.max_points < 0 || c.map_lo < 0 ||
+        c.map_hi > 255 || c.map_lo > c.map_hi || c.map_prior < 0 || c.map_prior > 255)
+        return fail(nullptr, PF_ERR_ARG, "pf_create: resolution/capacities/clamps");
+    if (c.order_mode < PF_ORDER_AUTO || c.order_mode > PF_ORDER_FAST)
+        return fail(nullptr, PF_ERR_ARG, "pf_create: order_mode");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, PF_ERR_NODEVICE, "pf_create: no HIP device (this library has no CPU path)");
+    if (c.device < 0 || c.device >= ndev)
+        return fail(nullptr, PF_ERR_NODEVICE, "pf_create: device %d of %d", c.device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c.device) != hipSuccess)
+        return fail(nullptr, PF_ERR_HIP, "pf_create: hipGetDeviceProperties");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PF_ERR_NODEVICE, "pf_create: device is %s, kernels are gfx950 only",
+                    prop.gcnArchName);
+
+    pf_handle* h = new (std::nothrow) pf_handle;
+    if (!h) return fail(nullptr, PF_ERR_NOMEM, "pf_create: host allocation");
+    h->cfg = c;
+    h->P = c.n_particles; h->Pg = c.n_particles_global; h->offset = c.particle_offset;
+    h->elements = (long long)c.grid_x * c.grid_y * c.grid_z;
+    h->local_elements = (long long)c.local_x * c.local_y * c.local_z;
+    h->slab = c.map_mode == PF_MAP_PER_PARTICLE ? round_up((unsigned long long)h->elements, 256) : 0;
+    h->exact = c.order_mode == PF_ORDER_EXACT || (c.order_mode == PF_ORDER_AUTO && h->Pg <= 2048);
+    // beam chunks: enough waves to fill 256 CUs x 4 SIMDs several times over
+    {
+        const int waves_x = (h->P + 63) / 64;
+        int ch = (8192 + waves_x - 1) / waves_x;
+        if (ch < 1) ch = 1;
+        if (ch > 1024) ch = 1024;
+        h->max_chunks = ch;
+    }
+#define CREATE_TRY(expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            int rc_ = fail(nullptr, e_ == hipErrorOutOfMemory ? PF_ERR_NOMEM : PF_ERR_HIP,   \
+                           "pf_create: %s failed: %s", #expr, hipGetErrorString(e_));        \
+            pf_destroy(h);                                                                   \
+            return rc_;                                                                      \
+        }                                                                                    \
+    } while (0)
+    CREATE_TRY(hipSetDevice(c.device));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t P = h->P, Pg = h->Pg;
+    CREATE_TRY(dalloc(&h->pose, PF_POSE_ROWS * P));
+    CREATE_TRY(dalloc(&h->w, Pg));
+    CREATE_TRY(dalloc(&h->logw, Pg));
+    CREATE_TRY(dalloc(&h->cdf, Pg + 1));
+    CREATE_TRY(dalloc(&h->scratch, Pg + 1));
+    CREATE_TRY(dalloc(&h->u, Pg));
+    const unsigned long long map_bytes =
+        c.map_mode == PF_MAP_PER_PARTICLE ? h->slab * P : round_up((unsigned long long)h->elements, 256);
+    CREATE_TRY(dalloc(&h->maps, (size_t)map_bytes));
+    if (h->local_elements)
+        CREATE_TRY(dalloc(&h->local, (size_t)round_up((unsigned long long)h->local_elements, 256)));
+    CREATE_TRY(dalloc(&h->beams, (size_t)c.max_beams));
+    CREATE_TRY(dalloc(&h->partial, (size_t)h->max_chunks * P));
+    CREATE_TRY(dalloc(&h->scores, P));
+    CREATE_TRY(dalloc(&h->draw, Pg));
+    CREATE_TRY(dalloc(&h->first, Pg));
+    CREATE_TRY(dalloc(&h->dup_anc, Pg));
+    CREATE_TRY(dalloc(&h->free_slot, Pg));
+    CREATE_TRY(dalloc(&h->slot_anc, Pg));
+    CREATE_TRY(dalloc(&h->best, 1));
+    CREATE_TRY(dalloc(&h->counters, 2));
+    CREATE_TRY(dalloc(&h->vox, (size_t)c.max_beams));
+    CREATE_TRY(dalloc(&h->points, 3 * (size_t)c.max_points));
+    CREATE_TRY(dalloc(&h->wpts, 3 * (size_t)c.max_points));
+    CREATE_TRY(dalloc(&h->ray_idx, (size_t)c.max_points));
+    h->h_pose.resize(PF_POSE_ROWS * P);
+    // S3P:47-51 initial state, S3P:71-77 prior
+    {
+        std::vector<double> x(P, 7.5), y(P, 7.5), z(P, 1.5), yaw(P, 0.0), w(Pg, 1.0 / (double)Pg);
+        upload_pose_rows(h, x.data(), y.data(), z.data(), yaw.data());
+        CREATE_TRY(hipMemcpyAsync(h->pose, h->h_pose.data(), sizeof(double) * PF_POSE_ROWS * P,
+                                  hipMemcpyHostToDevice, h->stream));
+        CREATE_TRY(hipMemcpyAsync(h->w, w.data(), sizeof(double) * Pg, hipMemcpyHostToDevice, h->stream));
+        CREATE_TRY(hipMemsetAsync(h->logw, 0, sizeof(float) * Pg, h->stream));
+        CREATE_TRY(hipMemsetAsync(h->best, 0, sizeof(int32_t), h->stream));
+        CREATE_TRY(pfk_fill_u8(h->stream, h->maps, map_bytes, c.map_prior));
+        if (h->local) CREATE_TRY(hipMemsetAsync(h->local, 0, (size_t)h->local_elements, h->stream));
+        CREATE_TRY(hipStreamSynchronize(h->stream));
+    }
+#undef CREATE_TRY
+    *out = h;
+    return PF_OK;
+}
+
+int pf_predict(pf_handle* h, const double* x, const double* y, const double* z, const double* yaw) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, x && y && z && yaw, "null pose array");
+    const double lim = 16777216.0 * h->cfg.resolution;      // |pos/res| < 2^24 keeps indices exact
+    for (int i = 0; i < h->P; ++i)
+        if (!(fabs(x[i]) < lim && fabs(y[i]) < lim && fabs(z[i]) < lim) || !isfinite(yaw[i]))
+            return fail(h, PF_ERR_ARG, "pf_predict: particle %d pose not finite or |pos/res| >= 2^24", i);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));             // staging buffer reuse
+    upload_pose_rows(h, x, y, z, yaw);
+    HIP_TRY(h, hipMemcpyAsync(h->pose, h->h_pose.data(), sizeof(double) * PF_POSE_ROWS * h->P,
+                              hipMemcpyHostToDevice, h->stream));
+    return PF_OK;
+}
+
+int pf_get_poses(pf_handle* h, double* x, double* y, double* z, double* yaw) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, x && y && z && yaw, "null pose array");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t n = sizeof(double) * (size_t)h->P;
+    double* dst[4] = {x, y, z, yaw};
+    for (int k = 0; k < 4; ++k)
+        HIP_TRY(h, hipMemcpyAsync(dst[k], h->pose + (size_t)k * h->P, n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+
+int pf_set_weights(pf_handle* h, const double* w) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, w, "null weights");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(h->w, w, sizeof(double) * (size_t)h->Pg, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+
+int pf_get_weights(pf_handle* h, double* w, float* logw) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, w, "null weights");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(w, h->w, sizeof(double) * (size_t)h->Pg, hipMemcpyDeviceToHost, h->stream));
+    if (logw)
+        HIP_TRY(h, hipMemcpyAsync(logw, h->logw, sizeof(float) * (size_t)h->Pg, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+
+int pf_fill_maps(pf_handle* h, int value) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, value >= 0 && value <= 255, "value");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const unsigned long long bytes = h->slab ? h->slab * (unsigned long long)h->P
+                                             : round_up((unsigned long long)h->elements, 256);
+    HIP_TRY(h, pfk_fill_u8(h->stream, h->maps, bytes, value));
+    return PF_OK;
+}
+
+int pf_write_map(pf_handle* h, int32_t i, const uint8_t* src) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, src, "null src");
+    if (h->slab) NEED(h, i >= 0 && i < h->P, "particle index"); else i = 0;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(h->maps + h->slab * (unsigned long long)i, src, (size_t)h->elements,
+                              hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+
+int pf_broadcast_map(pf_handle* h, const uint8_t* src) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, src, "null src");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(h->maps, src, (size_t)h->elements, hipMemcpyHostToDevice, h->stream));
+    if (h->slab)
+        for (int i = 1; i < h->P; ++i)
+            HIP_TRY(h, hipMemcpyAsync(h->maps + h->slab * (unsigned long long)i, h->maps,
+                                      (size_t)h->elements, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+
+int pf_read_map(pf_handle* h, int32_t i, uint8_t* dst) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, dst, "null dst");
+    if (h->slab) NEED(h, i >= 0 && i < h->P, "particle index"); else i = 0;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(dst, h->maps + h->slab * (unsigned long long)i, (size_t)h->elements,
+                              hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+
+int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32_t* bz,
+                 const int8_t* bv, int64_t n) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, n >= 0 && n <= h->cfg.max_beams, "n_beams beyond max_beams");
+    NEED(h, n == 0 || (bx && by && bz && bv), "null beam array");
+    h->h_beams.resize((size_t)n);
+    for (int64_t j = 0; j < n; ++j) {
+        if (bx[j] < -(1 << 20) || bx[j] > (1 << 20) || by[j] < -(1 << 20) || by[j] > (1 << 20) ||
+            bz[j] < -(1 << 20) || bz[j] > (1 << 20))
+            return fail(h, PF_ERR_ARG, "pf_set_beams: beam %lld offset beyond +-2^20 voxels", (long long)j);
+        PfBeam& b = h->h_beams[(size_t)j];
+        b.lx = (double)bx[j]; b.ly = (double)by[j]; b.lz = (double)bz[j];   // S3P:745-747 int->double
+        b.v = bv[j]; b.pad = 0;
+    }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (n)
+        HIP_TRY(h, hipMemcpyAsync(h->beams, h->h_beams.data(), sizeof(PfBeam) * (size_t)n,
+                                  hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->M = (int)n;
+    return PF_OK;
+}
+
+int pf_measure(pf_handle* h, int add_points) {
+    if (!h) return PF_ERR_ARG;
+    const bool fuse = add_points != 0 && h->cfg.map_mode == PF_MAP_PER_PARTICLE;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    int chunks = 1, bpc = h->M > 0 ? h->M : 1;
+    if (!fuse && h->M > 0) {
+        chunks = h->max_chunks;
+        const int min_bpc = 32;                       // do not split below 32 beams per chunk
+        if (chunks > (h->M + min_bpc - 1) / min_bpc) chunks = (h->M + min_bpc - 1) / min_bpc;
+        if (chunks < 1) chunks = 1;
+        bpc = (h->M + chunks - 1) / chunks;
+        chunks = (h->M + bpc - 1) / bpc;
+    }
+    {
+        Timed t(h, PF_K_MEASURE);
+        HIP_TRY(h, pfk_measure(h->stream, h->pose, h->P, h->maps, h->slab, h->beams, h->M, chunks, bpc,
+                               grid_params(h), fuse, h->partial));
+    }
+    HIP_TRY(h, pfk_reduce_scores(h->stream, h->partial, chunks, h->P, h->scores));
+    h->measured = true;
+    return PF_OK;
+}
+
+int pf_get_scores(pf_handle* h, int32_t* sum, int32_t* cnt) {
+    if (!h) return PF_ERR_ARG;
+    if (!h->measured) return fail(h, PF_ERR_STATE, "pf_get_scores before pf_measure");
+    NEED(h, sum && cnt, "null output");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    std::vector<int32_t> tmp(2 * (size_t)h->P);
+    HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->scores, sizeof(int2) * (size_t)h->P, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < h->P; ++i) { sum[i] = tmp[2 * (size_t)i]; cnt[i] = tmp[2 * (size_t)i + 1]; }
+    return PF_OK;
+}
+
+void* pf_scores_device(pf_handle* h) { return h ? (void*)h->scores : nullptr; }
+void* pf_poses_device(pf_handle* h) { return h ? (void*)h->pose : nullptr; }
+void* pf_stream(pf_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int pf_voxel_indices(pf_handle* h, int32_t i, int32_t* flat_out) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, i >= 0 && i < h->P, "particle index");
+    NEED(h, flat_out || h->M == 0, "null output");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, pfk_voxel_indices(h->stream, h->pose, h->P, i, h->beams, h->M, grid_params(h), h->vox));
+    if (h->M)
+        HIP_TRY(h, hipMemcpyAsync(flat_out, h->vox, sizeof(int32_t) * (size_t)h->M, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+
+int pf_weights(pf_handle* h, const void* scores_global_dev) {
+    if (!h) return PF_ERR_ARG;
+    if (!scores_global_dev) {
+        if (h->Pg != h->P) return fail(h, PF_ERR_ARG, "pf_weights: sharded handle needs the gathered scores");
+        if (!h->measured) return fail(h, PF_ERR_STATE, "pf_weights before pf_measure");
+    }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const int2* sc = scores_global_dev ? (const int2*)scores_global_dev : h->scores;
+    {
+        Timed t(h, PF_K_WEIGHTS);
+        HIP_TRY(h, pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact));
+    }
+    h->weighted = true;
+    return PF_OK;
+}
+
+int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int32_t* slot_anc_out,
+                int32_t* best_out, int64_t* nohit_out, int64_t* ambiguous_out) {
+    if (!h) return PF_ERR_ARG;
+    if (!h->weighted) return fail(h, PF_ERR_STATE, "pf_resample before pf_weights");
+    if (!u && !h->have_u) return fail(h, PF_ERR_ARG, "pf_resample: no thresholds resident");
+    if (h->Pg != h->P && !poses_global_dev)
+        return fail(h, PF_ERR_ARG, "pf_resample: sharded handle needs the gathered pose blocks");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (u) {
+        HIP_TRY(h, hipMemcpyAsync(h->u, u, sizeof(double) * (size_t)h->Pg, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->have_u = true;
+    }
+    unsigned long long cnt[2] = {0, 0};
+    long long ambiguous = 0;
+    {
+        Timed t(h, PF_K_RESAMPLE);
+        // FAST order: a parallel sum/scan differs from the sequential one by at most
+        // ~2*Pg*2^-53 per boundary (all partial sums <= ~1); 4x that as the band.
+        const double bound = h->exact ? 0.0 : 4.0 * (double)h->Pg * 1.1102230246251565e-16;
+        HIP_TRY(h, pfk_search(h->stream, h->cdf, h->u, h->Pg, bound, h->draw, h->counters));
+        if (!h->exact) {
+            HIP_TRY(h, hipMemcpyAsync(cnt, h->counters, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            ambiguous = (long long)cnt[1];
+            if (ambiguous) {      // settle them on the sequential-order CDF of the same weights
+                HIP_TRY(h, pfk_cdf_exact(h->stream, h->w, h->Pg, h->cdf));
+                HIP_TRY(h, pfk_search(h->stream, h->cdf, h->u, h->Pg, 0.0, h->draw, h->counters));
+            }
+        }
+        HIP_TRY(h, pfk_assign(h->stream, h->draw, h->Pg, h->first, h->dup_anc, h->free_slot, h->slot_anc));
+        HIP_TRY(h, pfk_apply(h->stream, h->slot_anc, h->Pg, h->P, h->offset, h->w, h->logw, h->pose,
+                             (const double*)poses_global_dev, h->slab ? h->maps : nullptr, h->slab,
+                             (unsigned long long)h->elements));
+        HIP_TRY(h, pfk_argmax(h->stream, h->w, h->Pg, h->best));
+    }
+    int32_t best = 0;
+    HIP_TRY(h, hipMemcpyAsync(cnt, h->counters, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&best, h->best, sizeof best, hipMemcpyDeviceToHost, h->stream));
+    if (slot_anc_out)
+        HIP_TRY(h, hipMemcpyAsync(slot_anc_out, h->slot_anc, sizeof(int32_t) * (size_t)h->Pg,
+                                  hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (best_out) *best_out = best;
+    if (nohit_out) *nohit_out = (int64_t)cnt[0];
+    if (ambiguous_out) *ambiguous_out = ambiguous;
+    h->weighted = false;
+    h->measured = false;
+    return PF_OK;
+}
+
+int pf_set_scan(pf_handle* h, const double* points, int64_t n_points, const int32_t* ray_idx,
+                int64_t n_rays) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, n_points >= 0 && n_points <= h->cfg.max_points, "n_points beyond max_points");
+    NEED(h, n_rays >= 0 && n_rays <= h->cfg.max_points, "n_rays beyond max_points");
+    NEED(h, (n_points == 0 || points) && (n_rays == 0 || ray_idx), "null array");
+    for (int64_t i = 0; i < 3 * n_points; ++i)
+        if (!(fabs(points[i]) < 1.0e6)) return fail(h, PF_ERR_ARG, "pf_set_scan: point %lld not finite/too far", (long long)(i / 3));
+    for (int64_t r = 0; r < n_rays; ++r)
+        if (ray_idx[r] < 0 || ray_idx[r] >= n_points)
+            return fail(h, PF_ERR_ARG, "pf_set_scan: ray_idx[%lld] outside [0, n_points)", (long long)r);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (n_points)
+        HIP_TRY(h, hipMemcpyAsync(h->points, points, sizeof(double) * 3 * (size_t)n_points, hipMemcpyHostToDevice, h->stream));
+    if (n_rays)
+        HIP_TRY(h, hipMemcpyAsync(h->ray_idx, ray_idx, sizeof(int32_t) * (size_t)n_rays, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->n_points = (int)n_points; h->n_rays = (int)n_rays;
+    return PF_OK;
+}
+
+int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const double pos[3],
+                  const double zyx[3]) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, p && pos && zyx, "null argument");
+    PfUpdateParams up;
+    void* grid = nullptr;
+    if (target == PF_GRID_SHARED) {
+        NEED(h, h->cfg.map_mode == PF_MAP_SHARED, "PF_GRID_SHARED needs map_mode PF_MAP_SHARED");
+        grid = h->maps; up.elements = h->elements; up.gy = h->cfg.grid_y; up.gz = h->cfg.grid_z;
+        up.is_signed = 0;
+        NEED(h, p->hit_clamp >= 0 && p->hit_clamp <= 255 && p->miss_clamp >= 0 && p->miss_clamp <= 255, "clamps outside uint8");
+    } else if (target == PF_GRID_LOCAL) {
+        NEED(h, h->local != nullptr, "no local map configured");
+        grid = h->local; up.elements = h->local_elements; up.gy = h->cfg.local_y; up.gz = h->cfg.local_z;
+        up.is_signed = 1;
+        NEED(h, p->hit_clamp >= -128 && p->hit_clamp <= 127 && p->miss_clamp >= -128 && p->miss_clamp <= 127, "clamps outside int8");
+    } else {
+        return fail(h, PF_ERR_ARG, "pf_update_map: target");
+    }
+    NEED(h, p->hit_inc >= 0 && p->hit_inc <= 127 && p->miss_inc <= 0 && p->miss_inc >= -127, "increments");
+    NEED(h, isfinite(pos[0]) && isfinite(pos[1]) && isfinite(pos[2]) && isfinite(zyx[0]) &&
+            isfinite(zyx[1]) && isfinite(zyx[2]) && fabs(pos[0]) < 1e6 && fabs(pos[1]) < 1e6 && fabs(pos[2]) < 1e6,
+         "pose not finite");
+    const double z = zyx[0], y = zyx[1], x = zyx[2];
+    up.rot[0] = cos(y) * cos(z);                                   // S3P:536-544, host libm
+    up.rot[1] = cos(z) * sin(x) * sin(y) - cos(x) * sin(z);
+    up.rot[2] = sin(x) * sin(z) + cos(x) * cos(z) * sin(y);
+    up.rot[3] = cos(y) * sin(z);
+    up.rot[4] = cos(x) * cos(z) + sin(x) * sin(y) * sin(z);
+    up.rot[5] = cos(x) * sin(y) * sin(z) - cos(z) * sin(x);
+    up.rot[6] = -sin(y);
+    up.rot[7] = cos(y) * sin(x);
+    up.rot[8] = cos(x) * cos(y);
+    up.pos[0] = pos[0]; up.pos[1] = pos[1]; up.pos[2] = pos[2];
+    up.conv = 1 / h->cfg.resolution;                               // S3P:284
+    up.max_range = p->max_range;
+    up.hit_inc = p->hit_inc; up.hit_clamp = p->hit_clamp;
+    up.miss_inc = p->miss_inc; up.miss_clamp = p->miss_clamp;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    Timed t(h, PF_K_UPDATE);
+    HIP_TRY(h, pfk_update_hits(h->stream, grid, h->points, h->n_points, h->wpts, up));
+    HIP_TRY(h, pfk_update_rays(h->stream, grid, h->wpts, h->ray_idx, h->n_rays, up));
+    return PF_OK;
+}
+
+int pf_write_local_map(pf_handle* h, const int8_t* src) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, src && h->local, "no local map / null src");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(h->local, src, (size_t)h->local_elements, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+int pf_read_local_map(pf_handle* h, int8_t* dst) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, dst && h->local, "no local map / null dst");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(dst, h->local, (size_t)h->local_elements, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+int pf_reset_local_map(pf_handle* h) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, h->local, "no local map");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemsetAsync(h->local, 0, (size_t)h->local_elements, h->stream));
+    return PF_OK;
+}
+
+int pf_synchronize(pf_handle* h) {
+    if (!h) return PF_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+
+int pf_profile(pf_handle* h, int enable) {
+    if (!h) return PF_ERR_ARG;
+    h->profile = enable != 0;
+    return PF_OK;
+}
+
+int pf_kernel_time(pf_handle* h, int id, double* total_ms, int64_t* launches) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, id >= 0 && id < PF_K_COUNT && total_ms && launches, "kernel id / null output");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    double tot = 0;
+    for (auto& e : h->ev[id]) {
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, e.a, e.b));
+        tot += ms;
+        h->ev_pool.push_back(e);
+    }
+    *total_ms = tot;
+    *launches = (int64_t)h->ev[id].size();
+    h->ev[id].clear();
+    return PF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Internal launch interface between the C ABI (pf_api.hip) and the gfx950 kernels
+// (pf_kernels.hip). Not part of the public boundary (include/slam_pf.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// One beam of the step's beam list as the kernels read it (32 B, one s_load_dwordx8):
+// the integer voxel offsets of S3P:875-877 already promoted to double (the promotion
+// S3P:745-747 performs per evaluation is done once per beam on the host).
+struct PfBeam {
+    double lx, ly, lz;
+    int32_t v;       // int8 local-map value (S3P:886, 895)
+    int32_t pad;
+};
+
+// Pose block: double [PF_POSE_ROWS][n] = x, y, z, yaw, cos, sin, x/res, y/res, z/res.
+#define PF_POSE_ROWS 9
+
+struct PfGridParams {
+    double gyz;         // gy*gz as double (S3P:85: x*(15/0.05)*(4/0.05))
+    double gzd;         // gz as double
+    double elements;    // gx*gy*gz as double
+    int32_t occ_threshold;
+    int32_t lo, hi;
+};
+
+// K1 (+K2): S3P:859-908. partial: int2 [n_chunks][P].
+hipError_t pfk_measure(hipStream_t st, const double* pose, int P, uint8_t* maps,
+                       unsigned long long map_stride, const PfBeam* beams, int M, int n_chunks,
+                       int beams_per_chunk, PfGridParams gp, bool fuse, int2* partial);
+hipError_t pfk_reduce_scores(hipStream_t st, const int2* partial, int n_chunks, int P, int2* scores);
+hipError_t pfk_voxel_indices(hipStream_t st, const double* pose, int P, int i, const PfBeam* beams,
+                             int M, PfGridParams gp, int32_t* flat_out);
+
+// K3: S3P:920-937. w in/out [Pg]; logw out [Pg]; cdf out [Pg+1]; scratch double [Pg+1].
+hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
+                       double* cdf, double* scratch, bool exact);
+// Sequential-order CDF of the current w (used to re-search ambiguous draws).
+hipError_t pfk_cdf_exact(hipStream_t st, const double* w, int Pg, double* cdf);
+
+// K4: S3P:757-821. counters: unsigned long long [2] = {nohit, ambiguous}, zeroed here.
+hipError_t pfk_search(hipStream_t st, const double* cdf, const double* u, int Pg, double bound,
+                      int32_t* draw, unsigned long long* counters);
+hipError_t pfk_assign(hipStream_t st, const int32_t* draw, int Pg, int32_t* first,
+                      int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc);
+hipError_t pfk_apply(hipStream_t st, const int32_t* slot_anc, int Pg, int P, int offset,
+                     double* w, float* logw, double* pose, const double* pose_gathered,
+                     uint8_t* maps, unsigned long long map_stride, unsigned long long map_bytes);
+hipError_t pfk_argmax(hipStream_t st, const double* w, int Pg, int32_t* best_inout);
+
+// K5: S3P:628-704. rot9: row-major ZYX matrix from the host libm. wpts: double [M][3] scratch.
+struct PfUpdateParams {
+    double rot[9];
+    double pos[3];
+    double conv;          // 1/resolution (S3P:284)
+    double max_range;
+    long long elements;
+    int32_t gy, gz;
+    int32_t hit_inc, hit_clamp, miss_inc, miss_clamp;
+    int32_t is_signed;
+};
+hipError_t pfk_update_hits(hipStream_t st, void* grid, const double* points, int M, double* wpts,
+                           PfUpdateParams up);
+hipError_t pfk_update_rays(hipStream_t st, void* grid, const double* wpts, const int32_t* ray_idx,
+                           int R, PfUpdateParams up);
+hipError_t pfk_fill_u8(hipStream_t st, uint8_t* dst, unsigned long long n, int value);

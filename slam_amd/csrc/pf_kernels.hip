@@ -1,0 +1,589 @@
+// gfx950 (CDNA4, wave64) kernels of the particle-filter hot path.
+// Compiled with -ffp-contract=off: the reference is scalar x86-64 code in which every fp64
+// product and sum rounds on its own (S3P:745-747, S3P:880, S3P:928); a fused multiply-add
+// would move round() across half-voxel boundaries. Where an fma() appears below it is on
+// integer-valued doubles whose exact result is representable, so fusing changes nothing.
+#include "pf_kernels.h"
+#include <limits.h>
+#include <math.h>
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------
+// K1 (+K2) measure: S3P:859-908.
+// Mapping: one LANE per particle, beams are wave-uniform. The pose (cos, sin, T) of the lane's
+// particle stays in VGPRs for the whole loop; each beam (32 B) arrives by one scalar load and
+// feeds the fp64 VALU as SGPR operands, so no LDS traffic, no cross-lane reduction and no
+// divergence on the beam's "occupied" test. The 64 gathers of one wave-instruction are the
+// same beam seen from 64 neighbouring hypotheses: they fall into a handful of cache lines.
+// Beams are split over blockIdx.y into chunks whose integer partial sums are added by
+// k_reduce_scores (integer addition: order-free, bit-exact).
+// FUSE (S3P:892-904, per-particle maps only): the lane walks ALL beams of its particle in
+// ascending order on its own slab, so the read-before-own-add / after-earlier-adds order of
+// the reference holds by construction (one chunk only).
+// ------------------------------------------------------------------------------------------
+template <bool FUSE>
+__global__ __launch_bounds__(256) void k_measure(
+        const double* __restrict__ pose, int P, uint8_t* maps, unsigned long long map_stride,
+        const PfBeam* __restrict__ beams, int M, int bpc, PfGridParams gp,
+        int2* __restrict__ partial) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int pc = p < P ? p : P - 1;
+    const double c = pose[4 * (size_t)P + pc];
+    const double s = pose[5 * (size_t)P + pc];
+    const double tx = pose[6 * (size_t)P + pc];
+    const double ty = pose[7 * (size_t)P + pc];
+    const double tz = pose[8 * (size_t)P + pc];
+    const double ms = -s;                       // S3P:734 with x = y = 0: exactly -sin(z)
+    uint8_t* map = maps + map_stride * (unsigned long long)pc;
+    const int j0 = blockIdx.y * bpc;
+    const int j1 = min(M, j0 + bpc);
+    int sum = 0, cnt = 0;
+    for (int j = j0; j < j1; ++j) {
+        const PfBeam b = beams[j];              // wave-uniform: scalar load
+        // S3P:745-747 (R02 = R12 = +-0, row 2 = (0,0,1)), S3P:880, S3P:85
+        const double X = round((c * b.lx + ms * b.ly) + tx);
+        const double Y = round((s * b.lx + c * b.ly) + ty);
+        const double Z = round(b.lz + tz);
+        const double fd = fma(X, gp.gyz, fma(Y, gp.gzd, Z));     // exact (integers < 2^53)
+        if (fd >= 0.0 && fd < gp.elements) {    // S3P:882 (== elements is out of bounds)
+            const unsigned f = (unsigned)(int)fd;
+            if (FUSE) {
+                const int cell = map[f];
+                if (b.v > gp.occ_threshold) { sum += cell; cnt += 1; }   // S3P:886-889
+                int nv = cell + b.v;            // S3P:895-904
+                nv = nv < gp.lo ? gp.lo : (nv > gp.hi ? gp.hi : nv);
+                map[f] = (uint8_t)nv;
+            } else if (b.v > gp.occ_threshold) {
+                sum += map[f];
+                cnt += 1;
+            }
+        }
+    }
+    if (p < P) partial[(size_t)blockIdx.y * P + p] = make_int2(sum, cnt);
+}
+
+__global__ __launch_bounds__(256) void k_reduce_scores(const int2* __restrict__ partial,
+                                                       int n_chunks, int P,
+                                                       int2* __restrict__ scores) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    int sx = 0, sy = 0;
+    for (int k = 0; k < n_chunks; ++k) {
+        const int2 v = partial[(size_t)k * P + p];
+        sx += v.x; sy += v.y;
+    }
+    scores[p] = make_int2(sx, sy);
+}
+
+__global__ __launch_bounds__(256) void k_voxel_indices(const double* __restrict__ pose, int P,
+                                                       int i, const PfBeam* __restrict__ beams,
+                                                       int M, PfGridParams gp,
+                                                       int32_t* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    const double c = pose[4 * (size_t)P + i], s = pose[5 * (size_t)P + i];
+    const double tx = pose[6 * (size_t)P + i], ty = pose[7 * (size_t)P + i];
+    const double tz = pose[8 * (size_t)P + i];
+    const double ms = -s;
+    const PfBeam b = beams[j];
+    const double X = round((c * b.lx + ms * b.ly) + tx);
+    const double Y = round((s * b.lx + c * b.ly) + ty);
+    const double Z = round(b.lz + tz);
+    const double fd = fma(X, gp.gyz, fma(Y, gp.gzd, Z));
+    out[j] = (fd >= 0.0 && fd < gp.elements) ? (int)fd : -1;
+}
+
+hipError_t pfk_measure(hipStream_t st, const double* pose, int P, uint8_t* maps,
+                       unsigned long long map_stride, const PfBeam* beams, int M, int n_chunks,
+                       int bpc, PfGridParams gp, bool fuse, int2* partial) {
+    dim3 grid((P + 255) / 256, n_chunks);
+    if (fuse)
+        hipLaunchKernelGGL(k_measure<true>, grid, dim3(256), 0, st, pose, P, maps, map_stride,
+                           beams, M, bpc, gp, partial);
+    else
+        hipLaunchKernelGGL(k_measure<false>, grid, dim3(256), 0, st, pose, P, maps, map_stride,
+                           beams, M, bpc, gp, partial);
+    return hipGetLastError();
+}
+
+hipError_t pfk_reduce_scores(hipStream_t st, const int2* partial, int n_chunks, int P,
+                             int2* scores) {
+    hipLaunchKernelGGL(k_reduce_scores, dim3((P + 255) / 256), dim3(256), 0, st, partial,
+                       n_chunks, P, scores);
+    return hipGetLastError();
+}
+
+hipError_t pfk_voxel_indices(hipStream_t st, const double* pose, int P, int i,
+                             const PfBeam* beams, int M, PfGridParams gp, int32_t* flat_out) {
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_voxel_indices, dim3((M + 255) / 256), dim3(256), 0, st, pose, P, i,
+                       beams, M, gp, flat_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// K3 weights: S3P:920-937. One workgroup of 1024 threads (16 waves on one CU): the vectors
+// are P doubles, the work is a handful of block-wide reductions. Reductions are a wave64
+// shuffle stage followed by an LDS stage of fixed shape, so every rank of a multi-GPU job
+// that runs this redundantly gets bit-identical results.
+// ------------------------------------------------------------------------------------------
+#define WG 1024
+#define TILE 4096
+#define NEVER_DRAWN 0x7f7f7f7f   // hipMemsetAsync(first, 0x7f): larger than any slot number
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+    return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, WAVE));
+    return v;
+}
+__device__ inline int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_down(v, o, WAVE));
+    return v;
+}
+// Block-wide reductions for WG threads; result broadcast to every thread. sh: 16 doubles.
+__device__ inline double block_sum(double v, double* sh) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    double r = 0;
+    for (int k = 0; k < WG / WAVE; ++k) r += sh[k];   // same order in every thread
+    return r;
+}
+__device__ inline double block_max(double v, double* sh) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    double r = sh[0];
+    for (int k = 1; k < WG / WAVE; ++k) r = fmax(r, sh[k]);
+    return r;
+}
+
+// Sequential-order sum of src[0..n) (S3P:929): tiles staged in LDS, one lane adds in order.
+__device__ inline double seq_sum(const double* src, int n, double* tile, double* sh) {
+    double run = 0;
+    for (int base = 0; base < n; base += TILE) {
+        const int cntv = min(TILE, n - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cntv; k += WG) tile[k] = src[base + k];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < cntv; ++k) run += tile[k];
+        }
+    }
+    if (threadIdx.x == 0) sh[0] = run;
+    __syncthreads();
+    run = sh[0];
+    __syncthreads();
+    return run;
+}
+
+// Sequential-order inclusive prefix sums (S3P:763-767): cdf[0] = 0, cdf[i+1] = cdf[i] + w[i].
+__device__ inline void seq_cdf(const double* w, int n, double* cdf, double* tile) {
+    __shared__ double carry;
+    if (threadIdx.x == 0) { carry = 0; cdf[0] = 0; }
+    for (int base = 0; base < n; base += TILE) {
+        const int cntv = min(TILE, n - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cntv; k += WG) tile[k] = w[base + k];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double run = carry;
+            for (int k = 0; k < cntv; ++k) { run += tile[k]; tile[k] = run; }
+            carry = run;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < cntv; k += WG) cdf[base + 1 + k] = tile[k];
+    }
+    __syncthreads();
+}
+
+// Fixed-shape parallel prefix sums: thread t owns the contiguous segment [t*seg, (t+1)*seg).
+__device__ inline void par_cdf(const double* w, int n, double* cdf, double* tile) {
+    const int seg = (n + WG - 1) / WG;
+    const int b = threadIdx.x * seg, e = min(n, b + seg);
+    double local = 0;
+    for (int k = b; k < e; ++k) local += w[k];
+    __syncthreads();
+    tile[threadIdx.x] = local;
+    __syncthreads();
+    for (int o = 1; o < WG; o <<= 1) {           // Hillis-Steele inclusive scan, fixed order
+        double add = threadIdx.x >= o ? tile[threadIdx.x - o] : 0.0;
+        __syncthreads();
+        tile[threadIdx.x] += add;
+        __syncthreads();
+    }
+    double run = threadIdx.x ? tile[threadIdx.x - 1] : 0.0;
+    if (threadIdx.x == 0) cdf[0] = 0;
+    for (int k = b; k < e; ++k) { run += w[k]; cdf[k + 1] = run; }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(WG) void k_weights(const int2* __restrict__ scores, int Pg, double* w,
+                                                float* __restrict__ logw, double* cdf,
+                                                double* scratch, int exact) {
+    __shared__ double tile[TILE];
+    __shared__ double sh[WG / WAVE];
+    __shared__ int shi[WG / WAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // S3P:920-925: smallest sum (ints: the order of the reduction does not matter).
+    int m = INT_MAX;
+    for (int g = tid; g < Pg; g += WG) m = min(m, scores[g].x);
+    m = wave_min_i(m);
+    if (lane == 0) shi[wv] = m;
+    __syncthreads();
+    m = shi[0];
+    for (int k = 1; k < WG / WAVE; ++k) m = min(m, shi[k]);
+    double smallest = 1000000000000.0;
+    if (smallest > (double)m) smallest = (double)m;
+    const double n_match = (double)scores[Pg - 1].y;     // S3P:865 + S3P:928: the LAST particle's
+    const double k99 = 0.99 * smallest;
+
+    // S3P:928: w <- ((w*a)*a)/num_match, a = s - 0.99*smallest. Beside it the log-domain
+    // value l = log w + 2 log a - log n for the max-subtract log-sum-exp.
+    double lmax = -INFINITY;
+    const double logn = log(n_match);
+    for (int g = tid; g < Pg; g += WG) {
+        const double a = (double)scores[g].x - k99;
+        const double w0 = w[g];
+        w[g] = w0 * a * a / n_match;
+        const double l = (w0 > 0.0 && a != 0.0) ? (log(w0) + 2.0 * log(fabs(a)) - logn)
+                                                  : -INFINITY;
+        scratch[g] = l;
+        lmax = fmax(lmax, l);
+    }
+    lmax = block_max(lmax, sh);
+    double se = 0;
+    for (int g = tid; g < Pg; g += WG) se += exp(scratch[g] - lmax);
+    se = block_sum(se, sh);
+    const double lse = lmax + log(se);
+    for (int g = tid; g < Pg; g += WG) logw[g] = (float)(scratch[g] - lse);
+
+    // S3P:929: sum of the raw weights.
+    double total;
+    if (exact) {
+        total = seq_sum(w, Pg, tile, sh);
+    } else {
+        double part = 0;
+        for (int g = tid; g < Pg; g += WG) part += w[g];
+        total = block_sum(part, sh);
+    }
+    // S3P:935-937 normalise, then S3P:763-767 prefix sums.
+    __syncthreads();
+    for (int g = tid; g < Pg; g += WG) w[g] = w[g] / total;
+    __syncthreads();
+    if (exact) seq_cdf(w, Pg, cdf, tile); else par_cdf(w, Pg, cdf, tile);
+}
+
+__global__ __launch_bounds__(WG) void k_cdf_exact(const double* w, int Pg, double* cdf) {
+    __shared__ double tile[TILE];
+    seq_cdf(w, Pg, cdf, tile);
+}
+
+hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
+                       double* cdf, double* scratch, bool exact) {
+    hipLaunchKernelGGL(k_weights, dim3(1), dim3(WG), 0, st, scores, Pg, w, logw, cdf, scratch,
+                       exact ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t pfk_cdf_exact(hipStream_t st, const double* w, int Pg, double* cdf) {
+    hipLaunchKernelGGL(k_cdf_exact, dim3(1), dim3(WG), 0, st, w, Pg, cdf);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// K4 resample: S3P:757-821.
+// ------------------------------------------------------------------------------------------
+// S3P:772-780 as a binary search. For a non-decreasing CDF the reference's first j with
+// cdf[j-1] < u < cdf[j] can only be j* = first j with cdf[j] > u, and it matches iff
+// cdf[j*-1] != u. No match (boundary hit, u above the last boundary, u == 0, NaN): the draw
+// keeps its own index and is counted.
+__global__ __launch_bounds__(256) void k_search(const double* __restrict__ cdf,
+                                                const double* __restrict__ u, int Pg, double bound,
+                                                int32_t* __restrict__ draw,
+                                                unsigned long long* counters) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Pg) return;
+    const double ui = u[i];
+    int lo = 1, hi = Pg + 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] > ui) hi = mid; else lo = mid + 1;
+    }
+    const bool hit = lo <= Pg && cdf[lo - 1] < ui;
+    draw[i] = hit ? lo - 1 : i;
+    if (!hit) atomicAdd(&counters[0], 1ull);
+    if (bound > 0.0) {
+        bool amb = !hit;
+        if (hit) amb = (ui - cdf[lo - 1] <= bound) || (cdf[lo] - ui <= bound);
+        if (amb) atomicAdd(&counters[1], 1ull);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_first(const int32_t* __restrict__ draw, int Pg,
+                                               int32_t* first) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < Pg) atomicMin(&first[draw[i]], i);
+}
+
+// S3P:782-802 in parallel form. A draw is a duplicate when its ancestor was drawn earlier
+// (first[a] != i); slot j is free when nobody drew it. The k-th duplicate (draw order) goes to
+// the k-th free slot (ascending); drawn slots keep themselves.
+__global__ __launch_bounds__(WG) void k_assign(const int32_t* __restrict__ draw, int Pg,
+                                               const int32_t* __restrict__ first,
+                                               int32_t* dup_anc, int32_t* free_slot,
+                                               int32_t* __restrict__ slot_anc) {
+    __shared__ int sd[WG], sf[WG];
+    const int tid = threadIdx.x;
+    const int seg = (Pg + WG - 1) / WG;
+    const int b = tid * seg, e = min(Pg, b + seg);
+    int nd = 0, nf = 0;
+    for (int k = b; k < e; ++k) {
+        nd += first[draw[k]] != k;
+        nf += first[k] == NEVER_DRAWN;
+    }
+    sd[tid] = nd; sf[tid] = nf;
+    __syncthreads();
+    for (int o = 1; o < WG; o <<= 1) {
+        const int ad = tid >= o ? sd[tid - o] : 0, af = tid >= o ? sf[tid - o] : 0;
+        __syncthreads();
+        sd[tid] += ad; sf[tid] += af;
+        __syncthreads();
+    }
+    int rd = tid ? sd[tid - 1] : 0, rf = tid ? sf[tid - 1] : 0;
+    for (int k = b; k < e; ++k) {
+        if (first[draw[k]] != k) dup_anc[rd++] = draw[k];
+        if (first[k] == NEVER_DRAWN) free_slot[rf++] = k; else slot_anc[k] = k;
+    }
+    __syncthreads();
+    __threadfence_block();
+    const int ndup = sd[WG - 1];
+    for (int k = tid; k < ndup; k += WG) slot_anc[free_slot[k]] = dup_anc[k];
+}
+
+// S3P:805-812. Sources are slots that keep themselves, so the in-place parallel copy reads
+// nothing that this launch writes.
+__global__ __launch_bounds__(256) void k_apply_w(const int32_t* __restrict__ slot_anc, int Pg,
+                                                 double* w, float* logw) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= Pg) return;
+    const int a = slot_anc[g];
+    if (a != g) { w[g] = w[a]; logw[g] = logw[a]; }
+}
+__global__ __launch_bounds__(256) void k_apply_pose(const int32_t* __restrict__ slot_anc, int P,
+                                                    int offset, double* pose,
+                                                    const double* __restrict__ gathered) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int g = offset + i;
+    const int a = slot_anc[g];
+    if (a == g) return;
+    if (gathered) {
+        const int r = a / P, ai = a - r * P;
+        const double* src = gathered + (size_t)r * PF_POSE_ROWS * P;
+#pragma unroll
+        for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * P + i] = src[(size_t)k * P + ai];
+    } else {
+        const int ai = a - offset;
+#pragma unroll
+        for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * P + i] = pose[(size_t)k * P + ai];
+    }
+}
+// Per-particle map slabs (S3P:810 copies the 7.2 MB map with the struct): 16 B per lane.
+__global__ __launch_bounds__(256) void k_apply_maps(const int32_t* __restrict__ slot_anc, int P,
+                                                    int offset, uint8_t* maps,
+                                                    unsigned long long stride,
+                                                    unsigned long long bytes) {
+    const int i = blockIdx.x;
+    const int a = slot_anc[offset + i];
+    if (a == offset + i) return;
+    const uint4* src = (const uint4*)(maps + stride * (unsigned long long)(a - offset));
+    uint4* dst = (uint4*)(maps + stride * (unsigned long long)i);
+    const unsigned long long n16 = (bytes + 15) / 16;        // slabs are padded to 256 B
+    for (unsigned long long k = (unsigned long long)blockIdx.y * 256 + threadIdx.x; k < n16;
+         k += (unsigned long long)gridDim.y * 256)
+        dst[k] = src[k];
+}
+
+// S3P:814-820: first index of the strict maximum above 0; otherwise the previous index stays.
+__global__ __launch_bounds__(WG) void k_argmax(const double* __restrict__ w, int Pg,
+                                               int32_t* best_inout) {
+    __shared__ double sv[WG];
+    __shared__ int si[WG];
+    const int tid = threadIdx.x;
+    double bv = 0.0; int bi = -1;
+    for (int g = tid; g < Pg; g += WG) {
+        const double v = w[g];
+        if (v > bv) { bv = v; bi = g; }          // ascending g per thread: first max kept
+    }
+    sv[tid] = bv; si[tid] = bi;
+    __syncthreads();
+    for (int o = WG / 2; o > 0; o >>= 1) {
+        if (tid < o) {
+            const double ov = sv[tid + o]; const int oi = si[tid + o];
+            if (oi >= 0 && (si[tid] < 0 || ov > sv[tid] || (ov == sv[tid] && oi < si[tid]))) {
+                sv[tid] = ov; si[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && si[0] >= 0) *best_inout = si[0];
+}
+
+hipError_t pfk_search(hipStream_t st, const double* cdf, const double* u, int Pg, double bound,
+                      int32_t* draw, unsigned long long* counters) {
+    hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_search, dim3((Pg + 255) / 256), dim3(256), 0, st, cdf, u, Pg, bound, draw,
+                       counters);
+    return hipGetLastError();
+}
+hipError_t pfk_assign(hipStream_t st, const int32_t* draw, int Pg, int32_t* first,
+                      int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc) {
+    hipError_t e = hipMemsetAsync(first, 0x7f, sizeof(int32_t) * (size_t)Pg, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_first, dim3((Pg + 255) / 256), dim3(256), 0, st, draw, Pg, first);
+    hipLaunchKernelGGL(k_assign, dim3(1), dim3(WG), 0, st, draw, Pg, first, dup_anc, free_slot,
+                       slot_anc);
+    return hipGetLastError();
+}
+hipError_t pfk_apply(hipStream_t st, const int32_t* slot_anc, int Pg, int P, int offset, double* w,
+                     float* logw, double* pose, const double* pose_gathered, uint8_t* maps,
+                     unsigned long long map_stride, unsigned long long map_bytes) {
+    hipLaunchKernelGGL(k_apply_w, dim3((Pg + 255) / 256), dim3(256), 0, st, slot_anc, Pg, w, logw);
+    hipLaunchKernelGGL(k_apply_pose, dim3((P + 255) / 256), dim3(256), 0, st, slot_anc, P, offset,
+                       pose, pose_gathered);
+    if (maps && map_stride) {
+        unsigned long long n16 = (map_bytes + 15) / 16;
+        int gy = (int)((n16 + 256ull * 8 - 1) / (256ull * 8));
+        if (gy < 1) gy = 1;
+        if (gy > 64) gy = 64;
+        hipLaunchKernelGGL(k_apply_maps, dim3(P, gy), dim3(256), 0, st, slot_anc, P, offset, maps,
+                           map_stride, map_bytes);
+    }
+    return hipGetLastError();
+}
+hipError_t pfk_argmax(hipStream_t st, const double* w, int Pg, int32_t* best_inout) {
+    hipLaunchKernelGGL(k_argmax, dim3(1), dim3(WG), 0, st, w, Pg, best_inout);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// K5 map update: S3P:628-704. Every touch of one phase applies the SAME function to a cell
+// (hits: v -> min(v+inc, clamp); misses: v -> max(v+inc, clamp)), so the result of a phase is
+// independent of the order of its touches and a compare-and-swap on the cell's 32-bit word
+// reproduces the reference's sequential loop exactly. Hits complete (kernel boundary) before
+// the ray march starts, as in S3P:632-661 then S3P:668-704.
+// ------------------------------------------------------------------------------------------
+__device__ inline void cell_touch(void* grid, long long f, int inc, int clampv, bool hit,
+                                  bool is_signed) {
+    unsigned* wp = (unsigned*)grid + (f >> 2);
+    const unsigned shft = (unsigned)(f & 3) * 8u;
+    unsigned old = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+        const unsigned byte = (old >> shft) & 0xffu;
+        const int v = is_signed ? (int)(int8_t)byte : (int)byte;
+        int nv = v + inc;
+        if (hit ? nv > clampv : nv < clampv) nv = clampv;
+        if (nv == v) return;
+        const unsigned nw = (old & ~(0xffu << shft)) | (((unsigned)nv & 0xffu) << shft);
+        const unsigned seen = atomicCAS(wp, old, nw);
+        if (seen == old) return;
+        old = seen;
+    }
+}
+
+// S3P:641-645: per-axis round, int flat index, flat-only bounds. Coordinates are validated on
+// the host to stay far inside int32, so the double arithmetic below is exact.
+__device__ inline long long flat_of(double rx, double ry, double rz, const PfUpdateParams& up) {
+    const double X = round(rx), Y = round(ry), Z = round(rz);
+    if (!(fabs(X) < 2147483648.0 && fabs(Y) < 2147483648.0 && fabs(Z) < 2147483648.0)) return -1;
+    const long long f = (long long)X * up.gy * up.gz + (long long)Y * up.gz + (long long)Z;
+    return (f < 0 || f >= up.elements) ? -1 : f;
+}
+
+__global__ __launch_bounds__(256) void k_update_hits(void* grid, const double* __restrict__ points,
+                                                     int M, double* __restrict__ wpts,
+                                                     PfUpdateParams up) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const double px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1],
+                 pz = points[3 * (size_t)i + 2];
+    // S3P:547-549 then S3P:555-557
+    const double wx = (up.rot[0] * px + up.rot[1] * py + up.rot[2] * pz) + up.pos[0];
+    const double wy = (up.rot[3] * px + up.rot[4] * py + up.rot[5] * pz) + up.pos[1];
+    const double wz = (up.rot[6] * px + up.rot[7] * py + up.rot[8] * pz) + up.pos[2];
+    wpts[3 * (size_t)i] = wx; wpts[3 * (size_t)i + 1] = wy; wpts[3 * (size_t)i + 2] = wz;
+    const double dx = wx - up.pos[0], dy = wy - up.pos[1], dz = wz - up.pos[2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);        // S3P:615-617
+    if (nrm > up.max_range) return;                              // S3P:637 (NaN falls through)
+    const long long f = flat_of(wx * up.conv, wy * up.conv, wz * up.conv, up);
+    if (f < 0) return;
+    cell_touch(grid, f, up.hit_inc, up.hit_clamp, true, up.is_signed != 0);
+}
+
+// One wave per ray; lane l takes steps j = 1+l, 65+l, ... (S3P:685: j = 1 .. n_it-1).
+__global__ __launch_bounds__(256) void k_update_rays(void* grid, const double* __restrict__ wpts,
+                                                     const int32_t* __restrict__ ray_idx, int R,
+                                                     PfUpdateParams up) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63;
+    const double* e = wpts + 3 * (size_t)ray_idx[r];
+    const double dx = e[0] - up.pos[0], dy = e[1] - up.pos[1], dz = e[2] - up.pos[2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    const double nc = nrm * up.conv;
+    const double rr = round(nc);                                 // S3P:676
+    if (!(rr < 2147483648.0)) return;                            // also drops NaN
+    const int n_it = (int)rr;
+    const double sx = dx / nc, sy = dy / nc, sz = dz / nc;       // S3P:681-683
+    for (int j = 1 + lane; j < n_it; j += WAVE) {
+        const double jd = (double)j;
+        const long long f = flat_of((up.pos[0] + sx * jd) * up.conv, (up.pos[1] + sy * jd) * up.conv,
+                                    (up.pos[2] + sz * jd) * up.conv, up);   // S3P:687-690
+        if (f >= 0) cell_touch(grid, f, up.miss_inc, up.miss_clamp, false, up.is_signed != 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_u8(uint4* dst, unsigned long long n16, uint4 v) {
+    for (unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x; k < n16;
+         k += (unsigned long long)gridDim.x * 256)
+        dst[k] = v;
+}
+
+hipError_t pfk_update_hits(hipStream_t st, void* grid, const double* points, int M, double* wpts,
+                           PfUpdateParams up) {
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_update_hits, dim3((M + 255) / 256), dim3(256), 0, st, grid, points, M,
+                       wpts, up);
+    return hipGetLastError();
+}
+hipError_t pfk_update_rays(hipStream_t st, void* grid, const double* wpts, const int32_t* ray_idx,
+                           int R, PfUpdateParams up) {
+    if (R == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_update_rays, dim3((R + 3) / 4), dim3(256), 0, st, grid, wpts, ray_idx, R,
+                       up);
+    return hipGetLastError();
+}
+hipError_t pfk_fill_u8(hipStream_t st, uint8_t* dst, unsigned long long n, int value) {
+    // dst is 256-B aligned and padded to a multiple of 16 by the allocator in pf_api.hip
+    const unsigned w = 0x01010101u * (unsigned)(value & 0xff);
+    const unsigned long long n16 = (n + 15) / 16;
+    unsigned long long blocks = (n16 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_u8, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)dst, n16,
+                       make_uint4(w, w, w, w));
+    return hipGetLastError();
+}

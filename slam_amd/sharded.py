@@ -1,0 +1,75 @@
+"""One rank of a multi-GPU filter: particles sharded in contiguous equal blocks, one process
+per GPU, torch.distributed (backend "nccl" = RCCL over xGMI) for the single exchange step.
+
+Per step and rank:
+  measure   local shard only, no communication (S3P:859-908 has no cross-particle dependence)
+  C1        all-gather of the (sum_match, num_match) pairs, 8 B per particle
+  weights   every rank computes min / weights / sum / CDF of ALL particles redundantly with the
+            same fixed-shape reductions, so all ranks agree bit for bit (S3P:920-937)
+  C2        all-gather of the 72-B pose blocks (shared-grid mode: the whole particle state), from
+            which each rank picks the ancestors of its own slots (S3P:805-812)
+  resample  redundantly on every rank; slot numbering is global, so slot_anc[] is identical to
+            the one-GPU run.
+The shared grid is replicated; every rank applies the identical update_map.
+"""
+import numpy as np
+
+
+class ShardedBackend:
+    def __init__(self, handle, dist, group=None):
+        """handle: slam_amd.capi.Handle created with n_particles = shard size,
+        n_particles_global, particle_offset = rank * shard size. dist: torch.distributed."""
+        import torch
+        self.torch = torch
+        self.h = handle
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.P = handle.P
+        self.Pg = handle.Pg
+        if self.P * self.world != self.Pg:
+            raise ValueError("shards must be equal: n_particles * world != n_particles_global")
+        s = handle.scores_tensor()
+        p = handle.poses_tensor()
+        self._scores_all = torch.empty((self.world,) + tuple(s.shape), dtype=s.dtype, device=s.device)
+        self._poses_all = torch.empty((self.world,) + tuple(p.shape), dtype=p.dtype, device=p.device)
+
+    # pass-through (local, no communication)
+    def set_beams(self, *a): self.h.set_beams(*a)
+    def measure(self, add): self.h.measure(add)
+    def predict(self, x, y, z, yaw): self.h.predict(x, y, z, yaw)
+    def get_poses(self): return self.h.get_poses()
+    def set_weights(self, w): self.h.set_weights(w)
+    def get_weights(self): return self.h.get_weights()
+    def set_scan(self, *a): self.h.set_scan(*a)
+    def update_map(self, *a): self.h.update_map(*a)
+
+    def _sync_device(self, t):
+        if t.is_cuda:
+            self.torch.cuda.current_stream(t.device).synchronize()
+
+    def weights(self):
+        self.h.synchronize()                       # local scores complete on the handle's stream
+        s = self.h.scores_tensor()
+        self.dist.all_gather_into_tensor(self._scores_all, s, group=self.group)     # C1
+        self._sync_device(self._scores_all)
+        self.h.weights(self._scores_all.data_ptr())
+
+    def resample(self, u):
+        self.h.synchronize()                       # uploaded poses complete
+        p = self.h.poses_tensor()
+        self.dist.all_gather_into_tensor(self._poses_all, p, group=self.group)      # C2
+        self._sync_device(self._poses_all)
+        return self.h.resample(u, self._poses_all.data_ptr())
+
+    def best_pose(self, best):
+        """(x, y, z, yaw) of global slot `best` after resampling, on every rank."""
+        r, i = divmod(int(best), self.P)
+        t = self.torch.empty(4, dtype=self.torch.float64, device=self._poses_all.device)
+        if r == self.rank:
+            x, y, z, yaw = self.h.get_poses()
+            t.copy_(self.torch.tensor([x[i], y[i], z[i], yaw[i]], dtype=self.torch.float64))
+        self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, r) if self.group else r,
+                            group=self.group)
+        return tuple(float(v) for v in t.cpu().numpy())

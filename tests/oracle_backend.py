@@ -1,0 +1,108 @@
+"""TEST DOUBLE: an object with slam_amd.capi.Handle's methods whose loops are the CPU oracle.
+
+Lives under tests/ on purpose. It lets the CPU suite drive the product's host-side code
+(slam_amd/filter.py, slam_amd/sharded.py) against the golden vectors and under gloo without a
+GPU. The product never imports it; the product's only backend is the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from oracle import binding as O
+
+
+class OracleHandle:
+    def __init__(self, P, Pg=None, offset=0, grid=None, per_particle=True, world=None, prior=50):
+        self.P = P
+        self.Pg = Pg if Pg is not None else P
+        self.offset = offset
+        self.grid = grid or O.ref_grid()
+        self.elements = self.grid.gx * self.grid.gy * self.grid.gz
+        self.per_particle = per_particle
+        n_maps = P if per_particle else 1
+        self.maps = np.full((n_maps, self.elements), prior, np.uint8)
+        if world is not None:
+            self.maps[:] = np.asarray(world, np.uint8).reshape(1, -1)
+        self.pose = np.zeros((9, P), np.float64)
+        self.pose[0] = 7.5; self.pose[1] = 7.5; self.pose[2] = 1.5
+        self.w = np.full(self.Pg, 1.0 / self.Pg)
+        self.logw = np.zeros(self.Pg, np.float32)
+        self.best = 0
+        self.scores = np.zeros((P, 2), np.int32)
+
+    # state
+    def predict(self, x, y, z, yaw):
+        self.pose[0] = x; self.pose[1] = y; self.pose[2] = z; self.pose[3] = yaw
+
+    def get_poses(self):
+        return [self.pose[k].copy() for k in range(4)]
+
+    def set_weights(self, w):
+        self.w[:] = w
+
+    def get_weights(self):
+        return self.w.copy(), self.logw.copy()
+
+    def read_map(self, i=0):
+        return self.maps[i if self.per_particle else 0].copy()
+
+    # measurement
+    def set_beams(self, bx, by, bz, bv):
+        self.beams = tuple(np.array(a) for a in (bx, by, bz, bv))
+
+    def measure(self, add_points):
+        fuse = bool(add_points) and self.per_particle
+        s, c = O.measure(self.grid, self.pose[0].copy(), self.pose[1].copy(), self.pose[2].copy(),
+                         self.pose[3].copy(), self.maps.reshape(-1),
+                         self.elements if self.per_particle else 0, *self.beams, fuse)
+        self.scores[:, 0] = s; self.scores[:, 1] = c
+
+    def get_scores(self):
+        return self.scores[:, 0].copy(), self.scores[:, 1].copy()
+
+    def scores_tensor(self):
+        return torch.from_numpy(self.scores)
+
+    def poses_tensor(self):
+        return torch.from_numpy(self.pose)
+
+    def synchronize(self):
+        pass
+
+    @staticmethod
+    def _from_ptr(ptr, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        buf = (C.c_char * n).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def weights(self, scores_global_ptr=None):
+        if scores_global_ptr:
+            sc = self._from_ptr(scores_global_ptr, (self.Pg, 2), np.int32)
+        else:
+            assert self.Pg == self.P
+            sc = self.scores
+        _, self.logw = O.weights(self.w, sc[:, 0].copy(), int(sc[-1, 1]))
+
+    def resample(self, u, poses_global_ptr=None, want_slots=True):
+        d, sa, best, nohit = O.resample(self.w, u, self.best)
+        self.best = best
+        if poses_global_ptr:
+            world = self.Pg // self.P
+            allp = self._from_ptr(poses_global_ptr, (world, 9, self.P), np.float64)
+            new = self.pose.copy()
+            for i in range(self.P):
+                a = sa[self.offset + i]
+                if a != self.offset + i:
+                    new[:, i] = allp[a // self.P, :, a % self.P]
+            self.pose = new
+        else:
+            rec = np.ascontiguousarray(self.pose.T)
+            O.permute(sa, rec)
+            self.pose = np.ascontiguousarray(rec.T)
+            if self.per_particle:
+                O.permute(sa, self.maps)
+        lw = self.logw.copy()
+        O.permute(sa, lw)
+        self.logw = lw
+        return sa, best, nohit, 0

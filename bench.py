@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — particle·beam likelihood evaluations per second (BASELINE.json's metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload at N=1: BASELINE.json configs[1] — 10k particles x 4k-beam scan on a 256^3 shared
+uint8 grid. N>1: the same per GPU (weak scaling): particles sharded in equal blocks, grid
+replicated, one RCCL all-gather of the scores and one of the pose blocks per step.
+
+A step = one pass of the hot path on inputs resident in HBM: measure (K1) -> weights (K3) ->
+resample (K4) -> update_map (K5, every beam cast). The caller-side uploads (pf_predict's
+poses, the beam list, the scan, the thresholds) happen before the timed region, as the
+contract's "inputs already resident" asks; DESIGN.md quotes the upload-inclusive rate.
+One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--particles", type=int, default=10000, help="per GPU")
+    ap.add_argument("--beams", type=int, default=4096)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-update", action="store_true", help="leave K5 out of the step")
+    return ap.parse_args()
+
+
+def cpu_baseline(sc, dims, P, M, seconds):
+    """The oracle (a port of the reference's loops, oracle/pf_oracle.c) timed on this host, one
+    thread — the reference runs this path on one thread (S3P:1107). Bounded sample: whole steps
+    of the same workload (measure + weights + resample + map update) until `seconds` elapse."""
+    from oracle import binding as O
+    g = O.ref_grid(*dims)
+    grid = sc["grid"].reshape(-1).copy()
+    ucfg = O.UpdateCfg(dims[0], dims[1], dims[2], 0.05, 0, 10, 100, -3, 0, 3.0)
+    w = np.full(P, 1.0 / P)
+    u = np.random.default_rng(3).random(P)
+    pos = sc["true_pose"][:3].copy(); zyx = np.array([sc["true_pose"][3], 0.0, 0.0])
+    reps, t0 = 0, time.perf_counter()
+    t_measure = 0.0
+    while True:
+        a = time.perf_counter()
+        s, c = O.measure(g, sc["x"], sc["y"], sc["z"], sc["yaw"], grid, 0, *sc["beams"], 0)
+        t_measure += time.perf_counter() - a
+        ww = w.copy()
+        O.weights(ww, s, int(c[-1]))
+        O.resample(ww, u, 0)
+        O.update_map(ucfg, grid.reshape(dims), pos, zyx, sc["points"], sc["ray_idx"])
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or reps >= 50:
+            break
+    return {"value": reps * P * M / el, "unit": "evals/s", "cores": 1, "kind": "port",
+            "measure_only_value": reps * P * M / t_measure,
+            "sample": f"{reps} whole steps of the N=1 workload ({P} particles x {M} beams, "
+                      f"{dims[0]}^3 grid) in {el:.1f} s, 1 thread, gcc -O2"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from slam_amd import capi, synth
+    from slam_amd.sharded import ShardedBackend
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    P, M, dims = a.particles, a.beams, (a.grid, a.grid, a.grid)
+    Pg = P * world
+    # the scene (grid, scan, beams) is the same on every rank; each rank owns its own particles
+    sc = synth.scene(dims, P, M, seed=0)
+    rng = np.random.default_rng(1000 + rank)
+    tp = sc["true_pose"]
+    sc["x"] = tp[0] + rng.normal(0, 0.03, P); sc["y"] = tp[1] + rng.normal(0, 0.03, P)
+    sc["z"] = tp[2] + rng.normal(0, 0.015, P); sc["yaw"] = tp[3] + rng.normal(0, 0.02, P)
+    M = len(sc["beams"][0])
+
+    cfg = capi.default_config(device=local_rank, n_particles=P, n_particles_global=Pg,
+                              particle_offset=rank * P, map_mode=capi.PF_MAP_SHARED,
+                              grid_x=dims[0], grid_y=dims[1], grid_z=dims[2],
+                              local_x=0, local_y=0, local_z=0, max_beams=max(M, 1),
+                              max_points=max(len(sc["points"]), 1))
+    h = capi.Handle(cfg)
+    be = ShardedBackend(h, dist) if world > 1 else h
+    h.write_map(0, sc["grid"])
+    h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+    h.set_weights(np.full(Pg, 1.0 / Pg))
+    h.set_beams(*sc["beams"])
+    h.set_scan(sc["points"], sc["ray_idx"])
+    u = capi.draw_uniform(3, Pg)                     # the same thresholds on every rank
+    upd = capi.UpdateParams(10, 100, -3, 0, 3.0)
+    pos = tp[:3].copy(); zyx = np.array([tp[3], 0.0, 0.0])
+
+    def step(first=False):
+        be.measure(0)
+        be.weights()
+        r = be.resample(u if first else None, want_slots=False)
+        if not a.no_update:
+            h.update_map(capi.PF_GRID_SHARED, upd, pos, zyx)
+        return r
+
+    def fence():
+        h.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    step(first=True)                                 # makes the thresholds resident
+    for _ in range(a.warmup):
+        step()
+    h.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    amb_total = nohit_total = 0
+    for _ in range(a.steps):
+        _, _, nohit, amb = step()
+        amb_total += amb; nohit_total += nohit
+    fence()
+    el = time.perf_counter() - t0
+    h.profile(False)
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    k1_ms, k1_n = h.kernel_time(capi.PF_K_MEASURE)
+    k3_ms, k3_n = h.kernel_time(capi.PF_K_WEIGHTS)
+    k4_ms, k4_n = h.kernel_time(capi.PF_K_RESAMPLE)
+    k5_ms, k5_n = h.kernel_time(capi.PF_K_UPDATE)
+
+    if rank == 0:
+        evals = float(Pg) * M * a.steps
+        k1_avg_s = k1_ms / max(k1_n, 1) * 1e-3
+        # algorithmic bytes of one K1 launch: one grid byte per eval, 48 B pose in and
+        # 8 B scores out per particle, 13 B per beam read once
+        k1_bytes = P * M * 1 + 56 * P + 13 * M
+        achieved = k1_bytes / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
+        out = {
+            "metric": "particle-beam likelihood evals/sec", "value": evals / el, "unit": "evals/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C2 per GPU: {P} particles x {M}-beam scan, {a.grid}^3 shared "
+                                   f"uint8 grid; step = measure+weights+resample"
+                                   + ("" if a.no_update else "+update_map(all beams cast)"),
+                       "particles_per_gpu": P, "particles_total": Pg, "beams": M,
+                       "grid": list(dims), "order": "fast" if Pg > 2048 else "exact",
+                       "ambiguous_draws": int(amb_total), "nohit_draws": int(nohit_total)},
+            "roofline": {"bound": "hbm", "kernel": "k_measure<false>", "achieved": achieved,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "algorithmic_bytes_per_launch": k1_bytes,
+                         "avg_launch_us": k1_avg_s * 1e6, "launches": int(k1_n),
+                         "k1_evals_per_s": P * M / k1_avg_s if k1_avg_s > 0 else 0.0},
+            "kernel_us": {"measure": k1_ms / max(k1_n, 1) * 1e3, "weights": k3_ms / max(k3_n, 1) * 1e3,
+                          "resample": k4_ms / max(k4_n, 1) * 1e3, "update": k5_ms / max(k5_n, 1) * 1e3},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, dims, P, M, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    h.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -32,8 +32,11 @@ class ShardedBackend:
             raise ValueError("shards must be equal: n_particles * world != n_particles_global")
         s = handle.scores_tensor()
         p = handle.poses_tensor()
-        self._scores_all = torch.empty((self.world,) + tuple(s.shape), dtype=s.dtype, device=s.device)
-        self._poses_all = torch.empty((self.world,) + tuple(p.shape), dtype=p.dtype, device=p.device)
+        # rank blocks concatenated along dim 0: [world*P, 2] and [world*9, P]
+        self._scores_all = torch.empty((self.world * s.shape[0], s.shape[1]), dtype=s.dtype,
+                                       device=s.device)
+        self._poses_all = torch.empty((self.world * p.shape[0], p.shape[1]), dtype=p.dtype,
+                                      device=p.device)
 
     # pass-through (local, no communication)
     def set_beams(self, *a): self.h.set_beams(*a)
@@ -56,12 +59,12 @@ class ShardedBackend:
         self._sync_device(self._scores_all)
         self.h.weights(self._scores_all.data_ptr())
 
-    def resample(self, u):
+    def resample(self, u=None, want_slots=True):
         self.h.synchronize()                       # uploaded poses complete
         p = self.h.poses_tensor()
         self.dist.all_gather_into_tensor(self._poses_all, p, group=self.group)      # C2
         self._sync_device(self._poses_all)
-        return self.h.resample(u, self._poses_all.data_ptr())
+        return self.h.resample(u, self._poses_all.data_ptr(), want_slots)
 
     def best_pose(self, best):
         """(x, y, z, yaw) of global slot `best` after resampling, on every rank."""

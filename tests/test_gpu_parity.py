@@ -1,0 +1,369 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI against the oracle on the same
+seeded inputs and against the vectors produced by the reference itself (tests/golden/).
+Bar: bit-exact for every integer, index and (in reference order) fp64 quantity; log-weights
+within 1e-5 relative, the tolerance BASELINE.json's north_star states."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from slam_amd import capi, synth
+from slam_amd.filter import ParticleMapStep
+
+pytestmark = pytest.mark.gpu
+ORIGIN = (100, 100, 30)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def local_from_sparse(idx, val, dims=(200, 200, 80)):
+    local = np.zeros(dims[0] * dims[1] * dims[2], np.int8)
+    local[idx] = val
+    return local.reshape(dims)
+
+
+def test_library_is_the_hip_build():
+    L = capi.lib()
+    assert os.path.samefile(capi.LIB_PATH, os.path.join(os.path.dirname(capi.__file__), "csrc",
+                                                        "libslam_pf.so"))
+    assert all(hasattr(L, s) for s in capi.SYMBOLS)
+
+
+@pytest.mark.parametrize("name", ["step_P50_add1", "step_P50_add0", "step_P100_add1",
+                                  "step_P100_add0"])
+def test_reference_single_step(golden_dir, name):
+    """One particle_map() call of the reference, reference sizes, per-particle maps."""
+    g = load(golden_dir, name + ".npz")
+    P = int(g["P"])
+    world = g["world"].reshape(-1)
+    local = local_from_sparse(g["local_idx"], g["local_val"])
+    beams = capi.snapshot_beams(local, ORIGIN)
+    h = capi.Handle(capi.default_config(n_particles=P))
+    try:
+        h.broadcast_map(world)
+        st = ParticleMapStep(h, P)
+        s_in = g["state_in"]
+        st.set_state(s_in[:, 0], s_in[:, 1], s_in[:, 2], s_in[:, 3], s_in[:, 4])
+        st.add_points = int(g["add"]); st.last_update[:] = g["last_in"]
+        # pre-resample weights first (bit-exact against the reference's cout stream)
+        h.set_beams(*beams)
+        # voxel indices of particle 0 against the oracle
+        vi = h.voxel_indices(0)
+        ov = O.voxel_indices(O.ref_grid(), *s_in[0, :4], beams[0], beams[1], beams[2])
+        assert np.array_equal(vi, ov)
+        slots = st.step(beams, g["local_pose"], g["global_pose"], g["noise"], g["u"])
+        out = g["state_out"]
+        w, logw = h.get_weights()
+        px, py, pz, pyaw = h.get_poses()
+        assert np.array_equal(px, out[:, 0]) and np.array_equal(py, out[:, 1])
+        assert np.array_equal(pz, out[:, 2]) and np.array_equal(pyaw, out[:, 3])
+        assert np.array_equal(st.x, out[:, 0]) and np.array_equal(st.yaw, out[:, 3])
+        assert np.array_equal(w, out[:, 4])
+        assert st.best == int(g["best"]) and st.last_nohit == 0 and st.last_ambiguous == 0
+        assert st.add_points == int(g["add_after"])
+        assert np.array_equal(st.feedback, g["feedback"])
+        # log-weights (permuted with the particles) within 1e-5 relative of log(reference weight)
+        ok = out[:, 4] > 0
+        assert np.allclose(logw[ok], np.log(out[ok, 4]), rtol=1e-5, atol=1e-6)
+        crc = np.array([zlib.crc32(h.read_map(i).tobytes()) for i in range(P)], np.uint32)
+        assert np.array_equal(crc, g["map_crc"])
+        for i in (0, 1, P - 1):
+            m = h.read_map(i)
+            idx = np.flatnonzero(m != world).astype(np.int32)
+            assert np.array_equal(idx, g[f"map{i}_idx"]) and np.array_equal(m[idx], g[f"map{i}_val"])
+        assert slots is not None and len(slots) == P
+    finally:
+        h.close()
+
+
+def test_reference_200_step_run(golden_dir):
+    """BASELINE.json configs[0] on the GPU: state CRC equal to the reference's at every step."""
+    g = load(golden_dir, "run_P100_200steps.npz")
+    P, steps = int(g["P"]), int(g["steps"])
+    h = capi.Handle(capi.default_config(n_particles=P))
+    try:
+        h.broadcast_map(g["world"].reshape(-1))
+        st = ParticleMapStep(h, P)
+        st.set_state(np.full(P, 7.5), np.full(P, 7.5), np.full(P, 1.5), np.zeros(P),
+                     np.full(P, 1.0 / P))
+        off = g["local_off"]
+        for t in range(steps):
+            local = local_from_sparse(g["local_idx"][off[t]:off[t + 1]],
+                                      g["local_val"][off[t]:off[t + 1]])
+            beams = capi.snapshot_beams(local, ORIGIN)
+            st.step(beams, g["local_pose"][t], g["global_pose"][t], g["noise"][t], g["u"][t])
+            assert st.best == int(g["best"][t]), t
+            assert np.array_equal(st.feedback, g["feedback"][t]), t
+            w, _ = h.get_weights()
+            state = np.ascontiguousarray(np.stack([st.x, st.y, st.z, st.yaw, w], 1))
+            assert zlib.crc32(state.tobytes()) == int(g["state_crc"][t]), t
+        px, py, pz, pyaw = h.get_poses()
+        w, _ = h.get_weights()
+        assert np.array_equal(np.stack([px, py, pz, pyaw, w], 1), g["state_final"])
+        crc = np.array([zlib.crc32(h.read_map(i).tobytes()) for i in range(P)], np.uint32)
+        assert np.array_equal(crc, g["map_crc"])
+    finally:
+        h.close()
+
+
+def _shared_cfg(P, dims, **kw):
+    return capi.default_config(n_particles=P, map_mode=capi.PF_MAP_SHARED, grid_x=dims[0],
+                               grid_y=dims[1], grid_z=dims[2], local_x=0, local_y=0, local_z=0,
+                               max_points=1 << 15, **kw)
+
+
+def _oracle_step(grid, sc, w0, u, best0=0):
+    g = O.ref_grid(*grid.shape)
+    s, c = O.measure(g, sc["x"], sc["y"], sc["z"], sc["yaw"], grid.reshape(-1), 0, *sc["beams"], 0)
+    w = w0.copy()
+    _, logw = O.weights(w, s, int(c[-1]))
+    w_pre = w.copy()
+    d, sa, best, nohit = O.resample(w, u, best0)
+    return s, c, w_pre, logw, sa, best, nohit, w
+
+
+@pytest.mark.parametrize("P,M,dims,order", [
+    (1, 64, (64, 64, 32), capi.PF_ORDER_EXACT),
+    (63, 100, (64, 64, 32), capi.PF_ORDER_EXACT),
+    (2000, 1500, (128, 128, 128), capi.PF_ORDER_AUTO),
+    (5000, 777, (128, 128, 64), capi.PF_ORDER_EXACT),
+])
+def test_shared_grid_step_exact_order(P, M, dims, order):
+    sc = synth.scene(dims, P, M, seed=P)
+    rng = np.random.default_rng(P)
+    w0 = rng.random(P) + 0.05; w0 /= w0.sum()
+    u = capi.draw_uniform(1234 + P, P)
+    s, c, w_pre, logw, sa, best, nohit, w_after = _oracle_step(sc["grid"], sc, w0, u)
+    h = capi.Handle(_shared_cfg(P, dims, order_mode=order))
+    try:
+        h.write_map(0, sc["grid"])
+        h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+        h.set_weights(w0)
+        h.set_beams(*sc["beams"])
+        h.measure(0)
+        gs, gc = h.get_scores()
+        assert np.array_equal(gs, s) and np.array_equal(gc, c)
+        for i in (0, P // 2, P - 1):
+            ov = O.voxel_indices(O.ref_grid(*dims), sc["x"][i], sc["y"][i], sc["z"][i],
+                                 sc["yaw"][i], *sc["beams"][:3])
+            assert np.array_equal(h.voxel_indices(i), ov)
+        h.weights()
+        gw, glw = h.get_weights()
+        assert np.array_equal(gw, w_pre)                       # reference order: bit-exact
+        ok = w_pre > 0
+        assert np.allclose(glw[ok], logw[ok], rtol=1e-5, atol=1e-6)
+        slots, gbest, gnohit, amb = h.resample(u)
+        assert np.array_equal(slots, sa) and gbest == best and gnohit == nohit and amb == 0
+        gw2, _ = h.get_weights()
+        assert np.array_equal(gw2, w_after)
+        px, py, pz, pyaw = h.get_poses()
+        assert np.array_equal(px, sc["x"][sa]) and np.array_equal(pyaw, sc["yaw"][sa])
+    finally:
+        h.close()
+
+
+def test_shared_grid_fast_order_large():
+    """FAST order at a size where the sequential chain would dominate: scores and resampled
+    indices bit-exact, weights within fp64 rounding, log-weights within 1e-5 relative."""
+    P, M, dims = 20000, 2048, (128, 128, 128)
+    sc = synth.scene(dims, P, M, seed=7)
+    w0 = np.full(P, 1.0 / P)
+    u = capi.draw_uniform(99, P)
+    s, c, w_pre, logw, sa, best, nohit, w_after = _oracle_step(sc["grid"], sc, w0, u)
+    h = capi.Handle(_shared_cfg(P, dims, order_mode=capi.PF_ORDER_FAST))
+    try:
+        h.write_map(0, sc["grid"])
+        h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+        h.set_weights(w0)
+        h.set_beams(*sc["beams"])
+        h.measure(0)
+        gs, gc = h.get_scores()
+        assert np.array_equal(gs, s) and np.array_equal(gc, c)
+        h.weights()
+        gw, glw = h.get_weights()
+        assert np.allclose(gw, w_pre, rtol=1e-12, atol=0)
+        assert np.allclose(glw, logw, rtol=1e-5, atol=1e-6)
+        slots, gbest, gnohit, amb = h.resample(u)
+        assert np.array_equal(slots, sa) and gbest == best and gnohit == nohit
+    finally:
+        h.close()
+
+
+def test_systematic_thresholds_same_kernel():
+    """north_star's systematic resampling = the same kernels fed (u0+i)/N."""
+    P, M, dims = 3000, 512, (64, 64, 64)
+    sc = synth.scene(dims, P, M, seed=3)
+    w0 = np.full(P, 1.0 / P)
+    u = (0.37 + np.arange(P)) / P
+    s, c, w_pre, logw, sa, best, nohit, w_after = _oracle_step(sc["grid"], sc, w0, u)
+    h = capi.Handle(_shared_cfg(P, dims, order_mode=capi.PF_ORDER_EXACT))
+    try:
+        h.write_map(0, sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+        h.set_weights(w0); h.set_beams(*sc["beams"]); h.measure(0); h.weights()
+        slots, gbest, gnohit, amb = h.resample(u)
+        assert np.array_equal(slots, sa) and gbest == best and gnohit == nohit
+    finally:
+        h.close()
+
+
+def test_edge_cases_bounds_aliasing_and_empty():
+    dims = (32, 24, 16)
+    P = 130
+    rng = np.random.default_rng(5)
+    grid = rng.integers(0, 101, dims).astype(np.uint8)
+    # poses near and beyond the grid faces: out-of-bounds flats and the flat-only aliasing of
+    # S3P:882 (y = -1 or z = gz alias into a neighbouring row) must match the oracle
+    x = rng.uniform(-0.3, 32 * 0.05 + 0.3, P); y = rng.uniform(-0.3, 24 * 0.05 + 0.3, P)
+    z = rng.uniform(-0.2, 16 * 0.05 + 0.2, P); yaw = rng.uniform(-3.2, 3.2, P)
+    M = 900
+    bx = rng.integers(-20, 21, M).astype(np.int32); by = rng.integers(-20, 21, M).astype(np.int32)
+    bz = rng.integers(-10, 11, M).astype(np.int32)
+    bv = rng.choice(np.array([-50, -3, 1, 20, 21, 50], np.int8), M)
+    og = O.ref_grid(*dims)
+    s, c = O.measure(og, x, y, z, yaw, grid.reshape(-1), 0, bx, by, bz, bv, 0)
+    h = capi.Handle(_shared_cfg(P, dims))
+    try:
+        h.write_map(0, grid); h.predict(x, y, z, yaw); h.set_beams(bx, by, bz, bv); h.measure(0)
+        gs, gc = h.get_scores()
+        assert np.array_equal(gs, s) and np.array_equal(gc, c)
+        for i in range(0, P, 13):
+            assert np.array_equal(h.voxel_indices(i),
+                                  O.voxel_indices(og, x[i], y[i], z[i], yaw[i], bx, by, bz))
+        # empty beam list: num_match = 0 -> the reference divides by zero (S3P:928): NaN weights,
+        # no draw matches, every particle keeps its slot, best index unchanged
+        h.set_beams(bx[:0], by[:0], bz[:0], bv[:0]); h.measure(0)
+        gs, gc = h.get_scores()
+        assert not gs.any() and not gc.any()
+        h.weights()
+        w, _ = h.get_weights()
+        assert np.isnan(w).all()
+        slots, best, nohit, amb = h.resample(capi.draw_uniform(1, P))
+        assert np.array_equal(slots, np.arange(P)) and nohit == P and best == 0
+    finally:
+        h.close()
+
+
+def test_zero_weight_particles_and_ragged_sizes():
+    for P in (2, 65, 1025):
+        rng = np.random.default_rng(P)
+        w0 = rng.random(P); w0[rng.random(P) < 0.5] = 0.0
+        if not w0.any():
+            w0[0] = 1.0
+        sc = synth.scene((48, 48, 32), P, 200, seed=P)
+        u = capi.draw_uniform(P, P)
+        s, c, w_pre, logw, sa, best, nohit, w_after = _oracle_step(sc["grid"], sc, w0, u)
+        h = capi.Handle(_shared_cfg(P, (48, 48, 32), order_mode=capi.PF_ORDER_EXACT))
+        try:
+            h.write_map(0, sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+            h.set_weights(w0); h.set_beams(*sc["beams"]); h.measure(0); h.weights()
+            gw, glw = h.get_weights()
+            assert np.array_equal(gw, w_pre)
+            assert np.all(np.isneginf(glw[w_pre == 0]))
+            slots, gbest, gnohit, amb = h.resample(u)
+            assert np.array_equal(slots, sa) and gbest == best and gnohit == nohit
+        finally:
+            h.close()
+
+
+def _update_case(signed, dims, seed):
+    rng = np.random.default_rng(seed)
+    M = 3000
+    pos = np.array([dims[0] * 0.025, dims[1] * 0.025, dims[2] * 0.02])
+    zyx = np.array([0.4, 0.05, -0.08])
+    d = rng.normal(size=(M, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = d * rng.uniform(0.2, 4.5, (M, 1))
+    pts[:5] = 0.0                                   # zero-length rays (norm 0 -> no steps)
+    ray_idx = rng.integers(0, M, 2400).astype(np.int32)
+    if signed:
+        grid = rng.integers(-50, 51, dims).astype(np.int8)
+        prm = (10, 50, -3, -50)
+    else:
+        grid = rng.integers(0, 101, dims).astype(np.uint8)
+        prm = (10, 100, -3, 0)
+    return grid, pos, zyx, pts, ray_idx, prm
+
+
+def test_update_map_local_int8_matches_oracle():
+    """S3P:628-704 on the reference's int8 local map. PARITY UNPINNED by the reference (see
+    oracle/pf_oracle.h): checked against the restatement."""
+    dims = (200, 200, 80)
+    grid, pos, zyx, pts, ray_idx, prm = _update_case(True, dims, 11)
+    cfg = O.UpdateCfg(dims[0], dims[1], dims[2], 0.05, 1, prm[0], prm[1], prm[2], prm[3], 3.0)
+    want = grid.copy()
+    O.update_map(cfg, want, pos, zyx, pts, ray_idx)
+    h = capi.Handle(capi.default_config(n_particles=1, grid_x=8, grid_y=8, grid_z=8))
+    try:
+        h.write_local_map(grid)
+        h.set_scan(pts, ray_idx)
+        h.update_map(capi.PF_GRID_LOCAL, capi.UpdateParams(*prm, 3.0), pos, zyx)
+        got = h.read_local_map().reshape(dims)
+        assert np.array_equal(got, want)
+        assert np.count_nonzero(want != grid) > 1000
+        h.reset_local_map()
+        assert not h.read_local_map().any()
+    finally:
+        h.close()
+
+
+def test_update_map_shared_uint8_matches_oracle():
+    dims = (128, 128, 96)
+    grid, pos, zyx, pts, ray_idx, prm = _update_case(False, dims, 12)
+    cfg = O.UpdateCfg(dims[0], dims[1], dims[2], 0.05, 0, prm[0], prm[1], prm[2], prm[3], 3.0)
+    want = grid.copy()
+    O.update_map(cfg, want, pos, zyx, pts, np.arange(len(pts), dtype=np.int32))
+    h = capi.Handle(_shared_cfg(4, dims))
+    try:
+        h.write_map(0, grid)
+        h.set_scan(pts, np.arange(len(pts), dtype=np.int32))      # north-star: every beam is cast
+        h.update_map(capi.PF_GRID_SHARED, capi.UpdateParams(*prm, 3.0), pos, zyx)
+        assert np.array_equal(h.read_map(0).reshape(dims), want)
+    finally:
+        h.close()
+
+
+def test_full_size_properties_c2():
+    """BASELINE configs[1] at full size (10k particles x 4k beams, 256^3 shared grid), through
+    size-independent properties: a sample of particles against the oracle, linearity of the
+    score in the beam list, and resampling invariants."""
+    P, M, dims = 10000, 4096, (256, 256, 256)
+    sc = synth.scene(dims, P, M, seed=0)
+    h = capi.Handle(_shared_cfg(P, dims))
+    try:
+        h.write_map(0, sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+        bx, by, bz, bv = sc["beams"]
+        h.set_beams(bx, by, bz, bv); h.measure(0)
+        s_all, c_all = h.get_scores()
+        pick = np.arange(0, P, 97)
+        og = O.ref_grid(*dims)
+        s, c = O.measure(og, sc["x"][pick], sc["y"][pick], sc["z"][pick], sc["yaw"][pick],
+                         sc["grid"].reshape(-1), 0, bx, by, bz, bv, 0)
+        assert np.array_equal(s_all[pick], s) and np.array_equal(c_all[pick], c)
+        # linearity: scores over two halves of the beam list add up to the score over the whole
+        half = M // 2
+        h.set_beams(bx[:half], by[:half], bz[:half], bv[:half]); h.measure(0)
+        s1, c1 = h.get_scores()
+        h.set_beams(bx[half:], by[half:], bz[half:], bv[half:]); h.measure(0)
+        s2, c2 = h.get_scores()
+        assert np.array_equal(s1 + s2, s_all) and np.array_equal(c1 + c2, c_all)
+        h.set_beams(bx, by, bz, bv); h.measure(0); h.weights()
+        w, logw = h.get_weights()
+        assert abs(w.sum() - 1.0) < 1e-9
+        assert np.allclose(np.exp(logw.astype(np.float64)), w, rtol=1e-5, atol=1e-12)
+        u = capi.draw_uniform(3, P)
+        slots, best, nohit, amb = h.resample(u)
+        assert nohit == 0
+        w2, _ = h.get_weights()
+        assert np.array_equal(w2, w[slots])
+        drawn = np.unique(slots)
+        assert np.array_equal(slots[drawn], drawn)             # survivors keep their slot
+        assert w2[best] == w2.max() and best == int(np.argmax(w2))
+        # the oracle on the same normalised weights gives the same slots (sequential CDF)
+        wc = w.copy()
+        d, sa, obest, onohit = O.resample(wc, u, 0)
+        assert np.array_equal(slots, sa) and obest == best
+    finally:
+        h.close()

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void k_measure(
         const PfBeam* __restrict__ beams, int M, int bpc, PfGridParams gp,
         int2* __restrict__ partial) {
     const int p = blockIdx.x * 256 + threadIdx.x;
-    const int pc = p < P ? p : P - 1;
+    if (p >= P) return;                         // no barrier below; surplus lanes must not touch a map
+    const int pc = p;
     const double c = pose[4 * (size_t)P + pc];
     const double s = pose[5 * (size_t)P + pc];
     const double tx = pose[6 * (size_t)P + pc];
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void k_measure(
             }
         }
     }
-    if (p < P) partial[(size_t)blockIdx.y * P + p] = make_int2(sum, cnt);
+    partial[(size_t)blockIdx.y * P + p] = make_int2(sum, cnt);
 }
 
 __global__ __launch_bounds__(256) void k_reduce_scores(const int2* __restrict__ partial,

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <string>
@@ -37,7 +38,12 @@ struct pf_handle {
     double* u = nullptr;               // [Pg]
     uint8_t* maps = nullptr;           // shared grid or P slabs
     int8_t* local = nullptr;           // local int8 map
-    PfBeam* beams = nullptr;           // [max_beams]
+    PfBeam* beams = nullptr;           // [max_beams] every beam (fuse path, voxel indices)
+    PfBeam* beams_occ = nullptr;       // [max_beams] occupied beams only (fast measure path)
+    PfBeamF* beams_occ_f = nullptr;    // [max_beams] the same in fp32
+    int M_occ = 0;                     // padded to a multiple of PF_BEAM_GROUP
+    int M_occ_real = 0;
+    double lmax_occ = 0;               // max over occupied beams of max(|lx|+|ly|, |lz|)
     int2* partial = nullptr;           // [max_chunks][P]
     int2* scores = nullptr;            // [P]
     int32_t* draw = nullptr;           // [Pg]
@@ -48,12 +54,20 @@ struct pf_handle {
     int32_t* best = nullptr;           // [1]
     unsigned long long* counters = nullptr;   // [2]
     int32_t* vox = nullptr;            // [max_beams]
+    int32_t* order = nullptr;          // [P] lane -> particle for K1
+    int32_t* order_keys = nullptr;     // [P]
+    int32_t* order_hist[2] = {nullptr, nullptr};   // [PF_ORDER_BUCKETS] each, used alternately
+    int order_flip = 0;
+    bool order_dirty = true;           // poses changed since order[] was built
     double* points = nullptr;          // [max_points][3]
     double* wpts = nullptr;            // [max_points][3]
     int32_t* ray_idx = nullptr;        // [max_points]
     // host staging
     std::vector<double> h_pose;
-    std::vector<PfBeam> h_beams;
+    std::vector<PfBeam> h_beams, h_beams_occ;
+    std::vector<PfBeamF> h_beams_occ_f;
+    int tune_chunks = 0;               // SLAM_PF_CHUNKS (development knob)
+    int force_exact_measure = 0;       // SLAM_PF_EXACT_MEASURE=1: fp64-only kernel
     int max_chunks = 1;
     int M = 0;                         // resident beams
     int n_points = 0, n_rays = 0;
@@ -165,9 +179,9 @@ void pf_destroy(pf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams,
+    void* ptrs[] = {h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
-                    h->slot_anc, h->best, h->counters, h->vox, h->points, h->wpts, h->ray_idx};
+                    h->slot_anc, h->best, h->counters, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : h->ev) for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -228,8 +242,10 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     h->exact = c.order_mode == PF_ORDER_EXACT || (c.order_mode == PF_ORDER_AUTO && h->Pg <= 2048);
     // beam chunks: enough waves to fill 256 CUs x 4 SIMDs several times over
     {
-        const int waves_x = (h->P + 63) / 64;
-        int ch = (8192 + waves_x - 1) / waves_x;
+        // at most 2048 blocks of 256 threads = one full residency of 256 CUs x 8 blocks: every
+        // block does the same amount of work, so a second, partly filled round would be a tail
+        const int blocks_x = (h->P + 255) / 256;
+        int ch = 2048 / blocks_x;
         if (ch < 1) ch = 1;
         if (ch > 1024) ch = 1024;
         h->max_chunks = ch;
@@ -259,6 +275,10 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     if (h->local_elements)
         CREATE_TRY(dalloc(&h->local, (size_t)round_up((unsigned long long)h->local_elements, 256)));
     CREATE_TRY(dalloc(&h->beams, (size_t)c.max_beams));
+    CREATE_TRY(dalloc(&h->beams_occ, (size_t)c.max_beams));
+    CREATE_TRY(dalloc(&h->beams_occ_f, (size_t)c.max_beams));
+    if (const char* e = getenv("SLAM_PF_CHUNKS")) h->tune_chunks = atoi(e);
+    if (const char* e = getenv("SLAM_PF_EXACT_MEASURE")) h->force_exact_measure = atoi(e);
     CREATE_TRY(dalloc(&h->partial, (size_t)h->max_chunks * P));
     CREATE_TRY(dalloc(&h->scores, P));
     CREATE_TRY(dalloc(&h->draw, Pg));
@@ -269,6 +289,12 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->best, 1));
     CREATE_TRY(dalloc(&h->counters, 2));
     CREATE_TRY(dalloc(&h->vox, (size_t)c.max_beams));
+    CREATE_TRY(dalloc(&h->order, P));
+    CREATE_TRY(dalloc(&h->order_keys, P));
+    CREATE_TRY(dalloc(&h->order_hist[0], (size_t)PF_ORDER_BUCKETS));
+    CREATE_TRY(dalloc(&h->order_hist[1], (size_t)PF_ORDER_BUCKETS));
+    CREATE_TRY(hipMemsetAsync(h->order_hist[0], 0, sizeof(int32_t) * PF_ORDER_BUCKETS, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->order_hist[1], 0, sizeof(int32_t) * PF_ORDER_BUCKETS, h->stream));
     CREATE_TRY(dalloc(&h->points, 3 * (size_t)c.max_points));
     CREATE_TRY(dalloc(&h->wpts, 3 * (size_t)c.max_points));
     CREATE_TRY(dalloc(&h->ray_idx, (size_t)c.max_points));
@@ -303,6 +329,7 @@ int pf_predict(pf_handle* h, const double* x, const double* y, const double* z, 
     upload_pose_rows(h, x, y, z, yaw);
     HIP_TRY(h, hipMemcpyAsync(h->pose, h->h_pose.data(), sizeof(double) * PF_POSE_ROWS * h->P,
                               hipMemcpyHostToDevice, h->stream));
+    h->order_dirty = true;
     return PF_OK;
 }
 
@@ -389,6 +416,8 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     NEED(h, n >= 0 && n <= h->cfg.max_beams, "n_beams beyond max_beams");
     NEED(h, n == 0 || (bx && by && bz && bv), "null beam array");
     h->h_beams.resize((size_t)n);
+    h->h_beams_occ.clear(); h->h_beams_occ_f.clear();
+    double lmax = 0;
     for (int64_t j = 0; j < n; ++j) {
         if (bx[j] < -(1 << 20) || bx[j] > (1 << 20) || by[j] < -(1 << 20) || by[j] > (1 << 20) ||
             bz[j] < -(1 << 20) || bz[j] > (1 << 20))
@@ -396,13 +425,37 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         PfBeam& b = h->h_beams[(size_t)j];
         b.lx = (double)bx[j]; b.ly = (double)by[j]; b.lz = (double)bz[j];   // S3P:745-747 int->double
         b.v = bv[j]; b.pad = 0;
+        if (b.v > h->cfg.occ_threshold) {                                   // S3P:886
+            h->h_beams_occ.push_back(b);
+            h->h_beams_occ_f.push_back(PfBeamF{(float)bx[j], (float)by[j], (float)bz[j], b.v});
+            lmax = fmax(lmax, fmax(fabs(b.lx) + fabs(b.ly), fabs(b.lz)));
+        }
     }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (n)
         HIP_TRY(h, hipMemcpyAsync(h->beams, h->h_beams.data(), sizeof(PfBeam) * (size_t)n,
                                   hipMemcpyHostToDevice, h->stream));
+    // pad the occupied lists to a multiple of PF_BEAM_GROUP with beams no pose can bring into
+    // the grid (|coordinate| ~ 2^22 voxels while |pos/res| < 2^24 ... the flat index stays far
+    // outside [0, elements) for every validated pose: 2^22*gy*gz dominates)
+    const int n_real_occ = (int)h->h_beams_occ.size();
+    while (h->h_beams_occ.size() % PF_BEAM_GROUP) {
+        PfBeam d{}; d.lx = -3.0e7; d.ly = 0; d.lz = 0; d.v = 127;
+        h->h_beams_occ.push_back(d);
+        h->h_beams_occ_f.push_back(PfBeamF{-3.0e7f, 0.f, 0.f, 127});
+    }
+    const size_t no = h->h_beams_occ.size();
+    if (no) {
+        HIP_TRY(h, hipMemcpyAsync(h->beams_occ, h->h_beams_occ.data(), sizeof(PfBeam) * no,
+                                  hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->beams_occ_f, h->h_beams_occ_f.data(), sizeof(PfBeamF) * no,
+                                  hipMemcpyHostToDevice, h->stream));
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->M = (int)n;
+    h->M_occ = (int)no;
+    h->M_occ_real = n_real_occ;
+    h->lmax_occ = lmax;
     return PF_OK;
 }
 
@@ -410,19 +463,38 @@ int pf_measure(pf_handle* h, int add_points) {
     if (!h) return PF_ERR_ARG;
     const bool fuse = add_points != 0 && h->cfg.map_mode == PF_MAP_PER_PARTICLE;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    int chunks = 1, bpc = h->M > 0 ? h->M : 1;
-    if (!fuse && h->M > 0) {
-        chunks = h->max_chunks;
+    // Without fuse only the occupied beams matter (S3P:886) and beams may be split over
+    // blockIdx.y; with fuse every beam is walked in order by one lane.
+    const int Mk = fuse ? h->M : h->M_occ;
+    int chunks = 1, bpc = Mk > 0 ? Mk : 1;
+    if (!fuse && Mk > 0) {
+        chunks = h->tune_chunks > 0 ? h->tune_chunks : h->max_chunks;
+        if (chunks > h->max_chunks) chunks = h->max_chunks;
         const int min_bpc = 32;                       // do not split below 32 beams per chunk
-        if (chunks > (h->M + min_bpc - 1) / min_bpc) chunks = (h->M + min_bpc - 1) / min_bpc;
+        if (chunks > (Mk + min_bpc - 1) / min_bpc) chunks = (Mk + min_bpc - 1) / min_bpc;
         if (chunks < 1) chunks = 1;
-        bpc = (h->M + chunks - 1) / chunks;
-        chunks = (h->M + bpc - 1) / bpc;
+        bpc = (Mk + chunks - 1) / chunks;
+        bpc = (bpc + PF_BEAM_GROUP - 1) / PF_BEAM_GROUP * PF_BEAM_GROUP;
+        chunks = (Mk + bpc - 1) / bpc;
+    }
+    if (!fuse && !h->force_exact_measure && h->order_dirty) {
+        HIP_TRY(h, pfk_order(h->stream, h->pose, h->P, h->order_keys, h->order_hist[h->order_flip],
+                             h->order_hist[h->order_flip ^ 1], h->order));
+        h->order_flip ^= 1;
+        h->order_dirty = false;
     }
     {
         Timed t(h, PF_K_MEASURE);
-        HIP_TRY(h, pfk_measure(h->stream, h->pose, h->P, h->maps, h->slab, h->beams, h->M, chunks, bpc,
-                               grid_params(h), fuse, h->partial));
+        if (fuse)
+            HIP_TRY(h, pfk_measure(h->stream, h->pose, h->P, h->maps, h->slab, h->beams, h->M, 1, bpc,
+                                   grid_params(h), true, h->partial));
+        else if (h->force_exact_measure)
+            HIP_TRY(h, pfk_measure(h->stream, h->pose, h->P, h->maps, h->slab, h->beams_occ, Mk, chunks,
+                                   bpc, grid_params(h), false, h->partial));
+        else
+            HIP_TRY(h, pfk_measure_fast(h->stream, h->pose, h->P, h->maps, h->slab, h->beams_occ_f,
+                                        h->beams_occ, Mk, chunks, bpc, grid_params(h), h->lmax_occ,
+                                        h->order, h->partial));
     }
     HIP_TRY(h, pfk_reduce_scores(h->stream, h->partial, chunks, h->P, h->scores));
     h->measured = true;
@@ -517,6 +589,7 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
                                   hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (best_out) *best_out = best;
+    h->order_dirty = true;
     if (nohit_out) *nohit_out = (int64_t)cnt[0];
     if (ambiguous_out) *ambiguous_out = ambiguous;
     h->weighted = false;

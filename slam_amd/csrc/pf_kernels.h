@@ -13,6 +13,12 @@ struct PfBeam {
     int32_t pad;
 };
 
+// The same beam for the fp32 filter of the fast measure kernel (16 B, one s_load_dwordx4).
+struct PfBeamF {
+    float lx, ly, lz;
+    int32_t v;
+};
+
 // Pose block: double [PF_POSE_ROWS][n] = x, y, z, yaw, cos, sin, x/res, y/res, z/res.
 #define PF_POSE_ROWS 9
 
@@ -28,6 +34,21 @@ struct PfGridParams {
 hipError_t pfk_measure(hipStream_t st, const double* pose, int P, uint8_t* maps,
                        unsigned long long map_stride, const PfBeam* beams, int M, int n_chunks,
                        int beams_per_chunk, PfGridParams gp, bool fuse, int2* partial);
+// The occupied-beam lists are padded to a multiple of PF_BEAM_GROUP with out-of-bounds beams;
+// M and bpc passed to pfk_measure_fast are multiples of it.
+#define PF_BEAM_GROUP 4
+// K1 fast form (no fuse): bf/bd hold the OCCUPIED beams only (v > occ_threshold); lmax =
+// max over them of max(|lx|+|ly|, |lz|). Exactness argument in pf_kernels.hip / DESIGN.md.
+hipError_t pfk_measure_fast(hipStream_t st, const double* pose, int P, const uint8_t* maps,
+                            unsigned long long map_stride, const PfBeamF* bf, const PfBeam* bd,
+                            int M, int n_chunks, int bpc, PfGridParams gp, double lmax,
+                            const int32_t* order, int2* partial);
+// Lane order for K1: order[lane] = particle, bucketed by (yaw, x, y). hist/next_hist: two
+// int32 [PF_ORDER_BUCKETS] buffers used alternately (hist must be zero on entry; the call
+// leaves next_hist zeroed). keys: int32 [P] scratch.
+#define PF_ORDER_BUCKETS 32768
+hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, int32_t* hist,
+                     int32_t* next_hist, int32_t* order);
 hipError_t pfk_reduce_scores(hipStream_t st, const int2* partial, int n_chunks, int P, int2* scores);
 hipError_t pfk_voxel_indices(hipStream_t st, const double* pose, int P, int i, const PfBeam* beams,
                              int M, PfGridParams gp, int32_t* flat_out);

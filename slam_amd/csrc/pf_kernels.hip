@@ -64,6 +64,125 @@ __global__ __launch_bounds__(256) void k_measure(
     partial[(size_t)blockIdx.y * P + p] = make_int2(sum, cnt);
 }
 
+// ------------------------------------------------------------------------------------------
+// K1 fast form (no fuse): the same lane-per-particle mapping with a floating-point FILTER in
+// front of the fp64 arithmetic. The voxel coordinate is first evaluated in fp32 (2 FMAs per
+// axis at full VALU rate instead of 4 half-rate fp64 operations plus a 6-instruction fp64
+// round). With E a rigorous bound on |fp32 value - reference fp64 value| (derivation in
+// E = 2^-22 (Lmax + max|T|) covers the three roundings of each path), a lane whose
+// fp32 value lies farther than E from every half-integer provably rounds to the same voxel as
+// the reference. If ANY lane of the wave is closer than that (about 2 % of the wave-beams at
+// C2 sizes), the whole wave recomputes that beam with the reference's fp64 sequence, so the
+// result is bit-exact by construction, not by tolerance. Only occupied beams (v > threshold)
+// are in this kernel's list: without fuse the others contribute nothing (S3P:886).
+// FLAT32: gx*gy*gz <= 2^24, so the flat index is exact in fp32 (in-range values are
+// representable; out-of-range values round monotonically and stay out of range).
+// ------------------------------------------------------------------------------------------
+// Per-lane constants of the fast kernels.
+struct FastLane {
+    double c, s, ms, tx, ty, tz;
+    float cf, sf, msf, txf, tyf, zpf, thr;
+};
+
+// z needs no per-beam rounding: lz is an integer, so round(fl64(lz + tz)) = lz + rint(tz)
+// unless tz lies within the filter's error of a half-integer. That is a property of the LANE,
+// decided once: such a lane gets thr = -1, which sends every beam of its wave down the
+// reference fp64 sequence.
+__device__ __forceinline__ void fast_lane_init(FastLane& L, const double* __restrict__ pose, int P,
+                                               int p, double lmax) {
+    L.c = pose[4 * (size_t)P + p];
+    L.s = pose[5 * (size_t)P + p];
+    L.tx = pose[6 * (size_t)P + p];
+    L.ty = pose[7 * (size_t)P + p];
+    L.tz = pose[8 * (size_t)P + p];
+    L.ms = -L.s;
+    L.cf = (float)L.c; L.sf = (float)L.s; L.msf = -L.sf;
+    L.txf = (float)L.tx; L.tyf = (float)L.ty;
+    const float tzf = (float)L.tz;
+    L.zpf = rintf(tzf);
+    const double tmax = fmax(fmax(fabs(L.tx), fabs(L.ty)), fabs(L.tz));
+    // accept when |fp32 value - nearest integer| < thr = 0.5 - E (rounded down with margin)
+    L.thr = (float)(0.5 - 2.5e-7 * (lmax + tmax) - 1.0e-7);
+    if (!(fabsf(tzf - L.zpf) < L.thr)) L.thr = -1.0f;
+}
+
+// Reference sequence S3P:745-747, 880, 85: flat index or a value >= elements.
+__device__ __forceinline__ unsigned exact_flat(const FastLane& L, const PfBeam d,
+                                               const PfGridParams& gp) {
+    const double X = round((L.c * d.lx + L.ms * d.ly) + L.tx);
+    const double Y = round((L.s * d.lx + L.c * d.ly) + L.ty);
+    const double Z = round(d.lz + L.tz);
+    const double fd = fma(X, gp.gyz, fma(Y, gp.gzd, Z));
+    return (fd >= 0.0 && fd < gp.elements) ? (unsigned)(int)fd : 0xffffffffu;
+}
+
+struct __attribute__((aligned(64))) PfBeamF4 { PfBeamF b[PF_BEAM_GROUP]; };
+
+// The beam list is padded by the host to a multiple of PF_BEAM_GROUP with beams that are out
+// of bounds for every pose, and chunks are multiples of it. Per group of four beams: one
+// 64-byte scalar load, four fp32 evaluations, ONE ambiguity test for the wave (the fp64
+// reference sequence then re-does only the beams that need it), four independent gathers in
+// flight. SHARED: the map base is wave-uniform (SGPR base + 32-bit lane offset).
+template <bool FLAT32, bool SHARED>
+__global__ __launch_bounds__(256) void k_measure_fast(
+        const double* __restrict__ pose, int P, const uint8_t* __restrict__ maps,
+        unsigned long long map_stride, const PfBeamF* __restrict__ bf,
+        const PfBeam* __restrict__ bd, int M, int bpc, PfGridParams gp, double lmax,
+        const int32_t* __restrict__ order, int2* __restrict__ partial) {
+    const int lane_id = blockIdx.x * 256 + threadIdx.x;
+    if (lane_id >= P) return;
+    // order[]: particles bucketed by (yaw, x, y) so that the 64 lanes of a wave are near-identical
+    // hypotheses and their gathers fall into few, mostly adjacent, cache lines (k_order_*).
+    const int p = order[lane_id];
+    FastLane L;
+    fast_lane_init(L, pose, P, p, lmax);
+    const float gyzf = (float)gp.gyz, gzf = (float)gp.gzd;
+    const unsigned elements = (unsigned)gp.elements;
+    const uint8_t* map = SHARED ? maps : maps + map_stride * (unsigned long long)p;
+    const int j0 = blockIdx.y * bpc;
+    const int j1 = min(M, j0 + bpc);
+    const PfBeamF4* __restrict__ bf4 = (const PfBeamF4*)bf;
+    int sum = 0, cnt = 0;
+    for (int j = j0; j < j1; j += PF_BEAM_GROUP) {
+        const PfBeamF4 g = bf4[j / PF_BEAM_GROUP];   // wave-uniform: one s_load_dwordx16
+        unsigned f[PF_BEAM_GROUP];
+        float dev[PF_BEAM_GROUP];
+#pragma unroll
+        for (int k = 0; k < PF_BEAM_GROUP; ++k) {
+            const PfBeamF b = g.b[k];
+            const float xf = fmaf(L.cf, b.lx, fmaf(L.msf, b.ly, L.txf));
+            const float yf = fmaf(L.sf, b.lx, fmaf(L.cf, b.ly, L.tyf));
+            const float rx = rintf(xf), ry = rintf(yf), rz = b.lz + L.zpf;
+            dev[k] = fmaxf(fabsf(xf - rx), fabsf(yf - ry));
+            if (FLAT32) {
+                // clamp to [-1, 2^24] before the conversion: negative -> huge unsigned, >= 2^24
+                // -> >= elements, both out of bounds
+                f[k] = (unsigned)(int)__builtin_amdgcn_fmed3f(fmaf(rx, gyzf, fmaf(ry, gzf, rz)),
+                                                              -1.0f, 16777216.0f);
+            } else {
+                const double fd = fma((double)rx, gp.gyz, fma((double)ry, gp.gzd, (double)rz));
+                f[k] = (fd >= 0.0 && fd < gp.elements) ? (unsigned)(int)fd : 0xffffffffu;
+            }
+        }
+        const float dmax = fmaxf(fmaxf(dev[0], dev[1]), fmaxf(dev[2], dev[3]));
+        if (__builtin_expect(__any(!(dmax < L.thr)), 0)) {
+#pragma unroll
+            for (int k = 0; k < PF_BEAM_GROUP; ++k)
+                if (__any(!(dev[k] < L.thr))) f[k] = exact_flat(L, bd[j + k], gp);
+        }
+        unsigned v[PF_BEAM_GROUP];
+#pragma unroll
+        for (int k = 0; k < PF_BEAM_GROUP; ++k) v[k] = map[min(f[k], elements - 1u)];
+#pragma unroll
+        for (int k = 0; k < PF_BEAM_GROUP; ++k) {
+            const bool inb = f[k] < elements;        // S3P:882
+            sum += inb ? (int)v[k] : 0;              // S3P:887-888
+            cnt += inb ? 1 : 0;
+        }
+    }
+    partial[(size_t)blockIdx.y * P + p] = make_int2(sum, cnt);
+}
+
 __global__ __launch_bounds__(256) void k_reduce_scores(const int2* __restrict__ partial,
                                                        int n_chunks, int P,
                                                        int2* __restrict__ scores) {
@@ -105,6 +224,79 @@ hipError_t pfk_measure(hipStream_t st, const double* pose, int P, uint8_t* maps,
     else
         hipLaunchKernelGGL(k_measure<false>, grid, dim3(256), 0, st, pose, P, maps, map_stride,
                            beams, M, bpc, gp, partial);
+    return hipGetLastError();
+}
+
+hipError_t pfk_measure_fast(hipStream_t st, const double* pose, int P, const uint8_t* maps,
+                            unsigned long long map_stride, const PfBeamF* bf, const PfBeam* bd,
+                            int M, int n_chunks, int bpc, PfGridParams gp, double lmax,
+                            const int32_t* order, int2* partial) {
+    dim3 grid((P + 255) / 256, n_chunks);
+    const bool f32 = gp.elements <= 16777216.0, shared = map_stride == 0;
+#define LAUNCH_FAST(A, B)                                                                        \
+    hipLaunchKernelGGL((k_measure_fast<A, B>), grid, dim3(256), 0, st, pose, P, maps, map_stride, \
+                       bf, bd, M, bpc, gp, lmax, order, partial)
+    if (f32 && shared) LAUNCH_FAST(true, true);
+    else if (f32) LAUNCH_FAST(true, false);
+    else if (shared) LAUNCH_FAST(false, true);
+    else LAUNCH_FAST(false, false);
+#undef LAUNCH_FAST
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Particle ordering for K1: a counting sort on a 15-bit key (6 bits of yaw in 0.002 rad steps,
+// 4 bits of x in half voxels, 5 bits of y in quarter voxels, each wrapping). It only decides which
+// particles share a wave; every per-particle result is independent of it, so the arbitrary
+// order inside a bucket (atomic arrival order) cannot change any output.
+// ------------------------------------------------------------------------------------------
+#define ORDER_BUCKETS 32768
+__device__ inline int order_key(const double* __restrict__ pose, int P, int i) {
+    const int yq = (int)floor(pose[3 * (size_t)P + i] * 500.0) & 63;
+    const int xq = (int)floor(pose[6 * (size_t)P + i] * 2.0) & 15;
+    const int yy = (int)floor(pose[7 * (size_t)P + i] * 4.0) & 31;
+    return (yq << 9) | (xq << 5) | yy;
+}
+__global__ __launch_bounds__(256) void k_order_hist(const double* __restrict__ pose, int P,
+                                                    int32_t* __restrict__ keys, int32_t* hist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int k = order_key(pose, P, i);
+    keys[i] = k;
+    atomicAdd(&hist[k], 1);
+}
+// exclusive scan of hist in place; zeroes the buffer the NEXT sort will count into
+__global__ __launch_bounds__(1024) void k_order_scan(int32_t* hist, int32_t* next_hist) {
+    __shared__ int sh[1024];
+    const int tid = threadIdx.x;
+    const int per = ORDER_BUCKETS / 1024;
+    int local[ORDER_BUCKETS / 1024];
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < per; ++k) { local[k] = hist[tid * per + k]; tot += local[k]; }
+    sh[tid] = tot;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int add = tid >= o ? sh[tid - o] : 0;
+        __syncthreads();
+        sh[tid] += add;
+        __syncthreads();
+    }
+    int run = tid ? sh[tid - 1] : 0;
+#pragma unroll
+    for (int k = 0; k < per; ++k) { hist[tid * per + k] = run; run += local[k]; next_hist[tid * per + k] = 0; }
+}
+__global__ __launch_bounds__(256) void k_order_scatter(const int32_t* __restrict__ keys, int P,
+                                                       int32_t* hist, int32_t* __restrict__ order) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    order[atomicAdd(&hist[keys[i]], 1)] = i;
+}
+hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, int32_t* hist,
+                     int32_t* next_hist, int32_t* order) {
+    hipLaunchKernelGGL(k_order_hist, dim3((P + 255) / 256), dim3(256), 0, st, pose, P, keys, hist);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, st, hist, next_hist);
+    hipLaunchKernelGGL(k_order_scatter, dim3((P + 255) / 256), dim3(256), 0, st, keys, P, hist, order);
     return hipGetLastError();
 }
 

@@ -96,6 +96,12 @@ const char* pf_last_error(const pf_handle* h);
  * the local shard's poses. The library computes cos/sin(yaw) with the host libm (as S3P:860
  * does through rot_matrix) and pos/resolution (S3P:862-864) on the host. */
 int pf_predict(pf_handle* h, const double* x, const double* y, const double* z, const double* yaw);
+/* The same for a caller whose poses already live on this GPU: pose_block_dev is a device
+ * pointer to a block laid out like pf_poses_device() (double [9][n_particles]: x, y, z, yaw,
+ * cos, sin, x/res, y/res, z/res), e.g. one that an earlier pf_predict produced. Copied on the
+ * handle's stream, no host work. Rows 4..8 must be the host-libm values of rows 0..3 for the
+ * results to match the reference bit for bit. */
+int pf_predict_device(pf_handle* h, const void* pose_block_dev);
 int pf_get_poses(pf_handle* h, double* x, double* y, double* z, double* yaw);
 /* weight vector of ALL n_particles_global particles (S3P:51; every rank holds the whole vector) */
 int pf_set_weights(pf_handle* h, const double* w_global);

@@ -19,7 +19,7 @@ PF_K_MEASURE, PF_K_WEIGHTS, PF_K_RESAMPLE, PF_K_UPDATE = 0, 1, 2, 3
 
 # every symbol include/slam_pf.h declares (tests check the library exports exactly these)
 SYMBOLS = (
-    "pf_default_config pf_create pf_destroy pf_last_error pf_predict pf_get_poses pf_set_weights "
+    "pf_default_config pf_create pf_destroy pf_last_error pf_predict pf_predict_device pf_get_poses pf_set_weights "
     "pf_get_weights pf_fill_maps pf_write_map pf_broadcast_map pf_read_map pf_set_beams "
     "pf_measure pf_get_scores pf_scores_device pf_voxel_indices pf_weights pf_resample "
     "pf_poses_device pf_set_scan pf_update_map pf_write_local_map pf_read_local_map "
@@ -127,6 +127,9 @@ class Handle:
         x, y, z, yaw = (_c(a, np.float64) for a in (x, y, z, yaw))
         assert len(x) == len(y) == len(z) == len(yaw) == self.P
         self._ck(lib().pf_predict(self._h, _p(x), _p(y), _p(z), _p(yaw)), "pf_predict")
+
+    def predict_device(self, pose_block_ptr):
+        self._ck(lib().pf_predict_device(self._h, C.c_void_p(pose_block_ptr)), "pf_predict_device")
 
     def get_poses(self):
         out = [np.empty(self.P, np.float64) for _ in range(4)]

@@ -51,8 +51,11 @@ struct pf_handle {
     int32_t* dup_anc = nullptr;        // [Pg]
     int32_t* free_slot = nullptr;      // [Pg]
     int32_t* slot_anc = nullptr;       // [Pg]
-    int32_t* best = nullptr;           // [1]
-    unsigned long long* counters = nullptr;   // [2]
+    int32_t* best = nullptr;           // inside `counters`' allocation: one D2H copy returns all
+    unsigned long long* h_result = nullptr;    // pinned host mirror of counters[3] + best
+    unsigned long long* counters = nullptr;   // [3]
+    PfResampleScratch rs{};            // block-level scratch of K3/K4
+    void* rs_mem = nullptr;
     int32_t* vox = nullptr;            // [max_beams]
     int32_t* order = nullptr;          // [P] lane -> particle for K1
     int32_t* order_keys = nullptr;     // [P]
@@ -181,10 +184,11 @@ void pf_destroy(pf_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
-                    h->slot_anc, h->best, h->counters, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
+                    h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : h->ev) for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -286,8 +290,26 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->dup_anc, Pg));
     CREATE_TRY(dalloc(&h->free_slot, Pg));
     CREATE_TRY(dalloc(&h->slot_anc, Pg));
-    CREATE_TRY(dalloc(&h->best, 1));
-    CREATE_TRY(dalloc(&h->counters, 2));
+    CREATE_TRY(dalloc(&h->counters, 4));            // [0..2] counters, [3] holds `best`
+    h->best = (int32_t*)(h->counters + 3);
+    CREATE_TRY(hipHostMalloc((void**)&h->h_result, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    {
+        // one allocation, carved: 6 double arrays of nb (+8 for prm), 2 int2 arrays, 1 int array, ndup
+        const size_t nb = (Pg + 255) / 256;
+        const size_t bytes = sizeof(double) * (8 + 5 * nb) + sizeof(int2) * 2 * nb + sizeof(int32_t) * (nb + 4);
+        CREATE_TRY(hipMalloc(&h->rs_mem, bytes));
+        char* q = (char*)h->rs_mem;
+        h->rs.prm = (double*)q; q += sizeof(double) * 8;
+        h->rs.bsum = (double*)q; q += sizeof(double) * nb;
+        h->rs.bmax = (double*)q; q += sizeof(double) * nb;
+        h->rs.bse = (double*)q; q += sizeof(double) * nb;
+        h->rs.boff = (double*)q; q += sizeof(double) * nb;
+        h->rs.bbest_v = (double*)q; q += sizeof(double) * nb;
+        h->rs.bcnt = (int2*)q; q += sizeof(int2) * nb;
+        h->rs.boff2 = (int2*)q; q += sizeof(int2) * nb;
+        h->rs.bbest_i = (int32_t*)q; q += sizeof(int32_t) * nb;
+        h->rs.ndup = (int32_t*)q;
+    }
     CREATE_TRY(dalloc(&h->vox, (size_t)c.max_beams));
     CREATE_TRY(dalloc(&h->order, P));
     CREATE_TRY(dalloc(&h->order_keys, P));
@@ -307,7 +329,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
                                   hipMemcpyHostToDevice, h->stream));
         CREATE_TRY(hipMemcpyAsync(h->w, w.data(), sizeof(double) * Pg, hipMemcpyHostToDevice, h->stream));
         CREATE_TRY(hipMemsetAsync(h->logw, 0, sizeof(float) * Pg, h->stream));
-        CREATE_TRY(hipMemsetAsync(h->best, 0, sizeof(int32_t), h->stream));
+        CREATE_TRY(hipMemsetAsync(h->counters, 0, 4 * sizeof(unsigned long long), h->stream));
         CREATE_TRY(pfk_fill_u8(h->stream, h->maps, map_bytes, c.map_prior));
         if (h->local) CREATE_TRY(hipMemsetAsync(h->local, 0, (size_t)h->local_elements, h->stream));
         CREATE_TRY(hipStreamSynchronize(h->stream));
@@ -329,6 +351,16 @@ int pf_predict(pf_handle* h, const double* x, const double* y, const double* z, 
     upload_pose_rows(h, x, y, z, yaw);
     HIP_TRY(h, hipMemcpyAsync(h->pose, h->h_pose.data(), sizeof(double) * PF_POSE_ROWS * h->P,
                               hipMemcpyHostToDevice, h->stream));
+    h->order_dirty = true;
+    return PF_OK;
+}
+
+int pf_predict_device(pf_handle* h, const void* pose_block_dev) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, pose_block_dev, "null pose block");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(h->pose, pose_block_dev, sizeof(double) * PF_POSE_ROWS * h->P,
+                              hipMemcpyDeviceToDevice, h->stream));
     h->order_dirty = true;
     return PF_OK;
 }
@@ -539,7 +571,7 @@ int pf_weights(pf_handle* h, const void* scores_global_dev) {
     const int2* sc = scores_global_dev ? (const int2*)scores_global_dev : h->scores;
     {
         Timed t(h, PF_K_WEIGHTS);
-        HIP_TRY(h, pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact));
+        HIP_TRY(h, pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact, h->rs));
     }
     h->weighted = true;
     return PF_OK;
@@ -558,40 +590,28 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->have_u = true;
     }
-    unsigned long long cnt[2] = {0, 0};
-    long long ambiguous = 0;
+    unsigned long long cnt[3] = {0, 0, 0};
     {
         Timed t(h, PF_K_RESAMPLE);
-        // FAST order: a parallel sum/scan differs from the sequential one by at most
-        // ~2*Pg*2^-53 per boundary (all partial sums <= ~1); 4x that as the band.
-        const double bound = h->exact ? 0.0 : 4.0 * (double)h->Pg * 1.1102230246251565e-16;
-        HIP_TRY(h, pfk_search(h->stream, h->cdf, h->u, h->Pg, bound, h->draw, h->counters));
-        if (!h->exact) {
-            HIP_TRY(h, hipMemcpyAsync(cnt, h->counters, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            ambiguous = (long long)cnt[1];
-            if (ambiguous) {      // settle them on the sequential-order CDF of the same weights
-                HIP_TRY(h, pfk_cdf_exact(h->stream, h->w, h->Pg, h->cdf));
-                HIP_TRY(h, pfk_search(h->stream, h->cdf, h->u, h->Pg, 0.0, h->draw, h->counters));
-            }
-        }
-        HIP_TRY(h, pfk_assign(h->stream, h->draw, h->Pg, h->first, h->dup_anc, h->free_slot, h->slot_anc));
-        HIP_TRY(h, pfk_apply(h->stream, h->slot_anc, h->Pg, h->P, h->offset, h->w, h->logw, h->pose,
-                             (const double*)poses_global_dev, h->slab ? h->maps : nullptr, h->slab,
-                             (unsigned long long)h->elements));
-        HIP_TRY(h, pfk_argmax(h->stream, h->w, h->Pg, h->best));
+        // FAST order: the parallel sum/scan differs from the sequential one by at most a few
+        // Pg*2^-53 per boundary (all partial sums <= ~1); 8x that as the band.
+        const double bound = h->exact ? 0.0 : 8.0 * (double)h->Pg * 1.1102230246251565e-16;
+        HIP_TRY(h, pfk_resample(h->stream, h->cdf, h->u, h->Pg, h->P, h->offset, bound, h->w, h->logw,
+                                h->pose, (const double*)poses_global_dev, h->slab ? h->maps : nullptr,
+                                h->slab, (unsigned long long)h->elements, h->draw, h->first, h->dup_anc,
+                                h->free_slot, h->slot_anc, h->best, h->counters, h->rs));
     }
-    int32_t best = 0;
-    HIP_TRY(h, hipMemcpyAsync(cnt, h->counters, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(&best, h->best, sizeof best, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_result, h->counters, 4 * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, h->stream));
     if (slot_anc_out)
         HIP_TRY(h, hipMemcpyAsync(slot_anc_out, h->slot_anc, sizeof(int32_t) * (size_t)h->Pg,
                                   hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (best_out) *best_out = best;
+    cnt[0] = h->h_result[0]; cnt[1] = h->h_result[1]; cnt[2] = h->h_result[2];
+    if (best_out) *best_out = (int32_t)(h->h_result[3] & 0xffffffffull);
     h->order_dirty = true;
-    if (nohit_out) *nohit_out = (int64_t)cnt[0];
-    if (ambiguous_out) *ambiguous_out = ambiguous;
+    if (nohit_out) *nohit_out = (int64_t)(cnt[1] ? cnt[2] : cnt[0]);
+    if (ambiguous_out) *ambiguous_out = (int64_t)cnt[1];
     h->weighted = false;
     h->measured = false;
     return PF_OK;

@@ -53,21 +53,34 @@ hipError_t pfk_reduce_scores(hipStream_t st, const int2* partial, int n_chunks, 
 hipError_t pfk_voxel_indices(hipStream_t st, const double* pose, int P, int i, const PfBeam* beams,
                              int M, PfGridParams gp, int32_t* flat_out);
 
+// Scratch of the multi-block weight/resample kernels; nb = ceil(Pg / 256).
+struct PfResampleScratch {
+    double* prm;        // [8]
+    double* bsum;       // [nb]
+    double* bmax;       // [nb]
+    double* bse;        // [nb]
+    double* boff;       // [nb]
+    double* bbest_v;    // [nb]
+    int2* bcnt;         // [nb]
+    int2* boff2;        // [nb]
+    int32_t* bbest_i;   // [nb]
+    int32_t* ndup;      // [1]
+};
+
 // K3: S3P:920-937. w in/out [Pg]; logw out [Pg]; cdf out [Pg+1]; scratch double [Pg+1].
 hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
-                       double* cdf, double* scratch, bool exact);
-// Sequential-order CDF of the current w (used to re-search ambiguous draws).
-hipError_t pfk_cdf_exact(hipStream_t st, const double* w, int Pg, double* cdf);
+                       double* cdf, double* scratch, bool exact, PfResampleScratch sc);
 
-// K4: S3P:757-821. counters: unsigned long long [2] = {nohit, ambiguous}, zeroed here.
-hipError_t pfk_search(hipStream_t st, const double* cdf, const double* u, int Pg, double bound,
-                      int32_t* draw, unsigned long long* counters);
-hipError_t pfk_assign(hipStream_t st, const int32_t* draw, int Pg, int32_t* first,
-                      int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc);
-hipError_t pfk_apply(hipStream_t st, const int32_t* slot_anc, int Pg, int P, int offset,
-                     double* w, float* logw, double* pose, const double* pose_gathered,
-                     uint8_t* maps, unsigned long long map_stride, unsigned long long map_bytes);
-hipError_t pfk_argmax(hipStream_t st, const double* w, int Pg, int32_t* best_inout);
+// K4: S3P:757-821, the whole chain on the stream, no host round trip: search (+ re-search of
+// ambiguous draws on the sequential-order CDF when bound > 0), slot assignment, permutation of
+// weights / pose rows / map slabs, arg-max. counters: unsigned long long [3] = {no-hit draws,
+// ambiguous draws, no-hit draws after the re-search}.
+hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int Pg, int P,
+                        int offset, double bound, double* w, float* logw, double* pose,
+                        const double* pose_gathered, uint8_t* maps, unsigned long long map_stride,
+                        unsigned long long map_bytes, int32_t* draw, int32_t* first,
+                        int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
+                        unsigned long long* counters, PfResampleScratch sc);
 
 // K5: S3P:628-704. rot9: row-major ZYX matrix from the host libm. wpts: double [M][3] scratch.
 struct PfUpdateParams {

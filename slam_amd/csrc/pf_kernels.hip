@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void k_reduce_scores(const int2* __restrict__ 
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
     int sx = 0, sy = 0;
+#pragma unroll 8
     for (int k = 0; k < n_chunks; ++k) {
         const int2 v = partial[(size_t)k * P + p];
         sx += v.x; sy += v.y;
@@ -312,363 +313,6 @@ hipError_t pfk_voxel_indices(hipStream_t st, const double* pose, int P, int i,
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(k_voxel_indices, dim3((M + 255) / 256), dim3(256), 0, st, pose, P, i,
                        beams, M, gp, flat_out);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// K3 weights: S3P:920-937. One workgroup of 1024 threads (16 waves on one CU): the vectors
-// are P doubles, the work is a handful of block-wide reductions. Reductions are a wave64
-// shuffle stage followed by an LDS stage of fixed shape, so every rank of a multi-GPU job
-// that runs this redundantly gets bit-identical results.
-// ------------------------------------------------------------------------------------------
-#define WG 1024
-#define TILE 4096
-#define NEVER_DRAWN 0x7f7f7f7f   // hipMemsetAsync(first, 0x7f): larger than any slot number
-
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
-    return v;
-}
-__device__ inline double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, WAVE));
-    return v;
-}
-__device__ inline int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_down(v, o, WAVE));
-    return v;
-}
-// Block-wide reductions for WG threads; result broadcast to every thread. sh: 16 doubles.
-__device__ inline double block_sum(double v, double* sh) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    v = wave_sum(v);
-    __syncthreads();
-    if (lane == 0) sh[wv] = v;
-    __syncthreads();
-    double r = 0;
-    for (int k = 0; k < WG / WAVE; ++k) r += sh[k];   // same order in every thread
-    return r;
-}
-__device__ inline double block_max(double v, double* sh) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    v = wave_max(v);
-    __syncthreads();
-    if (lane == 0) sh[wv] = v;
-    __syncthreads();
-    double r = sh[0];
-    for (int k = 1; k < WG / WAVE; ++k) r = fmax(r, sh[k]);
-    return r;
-}
-
-// Sequential-order sum of src[0..n) (S3P:929): tiles staged in LDS, one lane adds in order.
-__device__ inline double seq_sum(const double* src, int n, double* tile, double* sh) {
-    double run = 0;
-    for (int base = 0; base < n; base += TILE) {
-        const int cntv = min(TILE, n - base);
-        __syncthreads();
-        for (int k = threadIdx.x; k < cntv; k += WG) tile[k] = src[base + k];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int k = 0; k < cntv; ++k) run += tile[k];
-        }
-    }
-    if (threadIdx.x == 0) sh[0] = run;
-    __syncthreads();
-    run = sh[0];
-    __syncthreads();
-    return run;
-}
-
-// Sequential-order inclusive prefix sums (S3P:763-767): cdf[0] = 0, cdf[i+1] = cdf[i] + w[i].
-__device__ inline void seq_cdf(const double* w, int n, double* cdf, double* tile) {
-    __shared__ double carry;
-    if (threadIdx.x == 0) { carry = 0; cdf[0] = 0; }
-    for (int base = 0; base < n; base += TILE) {
-        const int cntv = min(TILE, n - base);
-        __syncthreads();
-        for (int k = threadIdx.x; k < cntv; k += WG) tile[k] = w[base + k];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double run = carry;
-            for (int k = 0; k < cntv; ++k) { run += tile[k]; tile[k] = run; }
-            carry = run;
-        }
-        __syncthreads();
-        for (int k = threadIdx.x; k < cntv; k += WG) cdf[base + 1 + k] = tile[k];
-    }
-    __syncthreads();
-}
-
-// Fixed-shape parallel prefix sums: thread t owns the contiguous segment [t*seg, (t+1)*seg).
-__device__ inline void par_cdf(const double* w, int n, double* cdf, double* tile) {
-    const int seg = (n + WG - 1) / WG;
-    const int b = threadIdx.x * seg, e = min(n, b + seg);
-    double local = 0;
-    for (int k = b; k < e; ++k) local += w[k];
-    __syncthreads();
-    tile[threadIdx.x] = local;
-    __syncthreads();
-    for (int o = 1; o < WG; o <<= 1) {           // Hillis-Steele inclusive scan, fixed order
-        double add = threadIdx.x >= o ? tile[threadIdx.x - o] : 0.0;
-        __syncthreads();
-        tile[threadIdx.x] += add;
-        __syncthreads();
-    }
-    double run = threadIdx.x ? tile[threadIdx.x - 1] : 0.0;
-    if (threadIdx.x == 0) cdf[0] = 0;
-    for (int k = b; k < e; ++k) { run += w[k]; cdf[k + 1] = run; }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(WG) void k_weights(const int2* __restrict__ scores, int Pg, double* w,
-                                                float* __restrict__ logw, double* cdf,
-                                                double* scratch, int exact) {
-    __shared__ double tile[TILE];
-    __shared__ double sh[WG / WAVE];
-    __shared__ int shi[WG / WAVE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-
-    // S3P:920-925: smallest sum (ints: the order of the reduction does not matter).
-    int m = INT_MAX;
-    for (int g = tid; g < Pg; g += WG) m = min(m, scores[g].x);
-    m = wave_min_i(m);
-    if (lane == 0) shi[wv] = m;
-    __syncthreads();
-    m = shi[0];
-    for (int k = 1; k < WG / WAVE; ++k) m = min(m, shi[k]);
-    double smallest = 1000000000000.0;
-    if (smallest > (double)m) smallest = (double)m;
-    const double n_match = (double)scores[Pg - 1].y;     // S3P:865 + S3P:928: the LAST particle's
-    const double k99 = 0.99 * smallest;
-
-    // S3P:928: w <- ((w*a)*a)/num_match, a = s - 0.99*smallest. Beside it the log-domain
-    // value l = log w + 2 log a - log n for the max-subtract log-sum-exp.
-    double lmax = -INFINITY;
-    const double logn = log(n_match);
-    for (int g = tid; g < Pg; g += WG) {
-        const double a = (double)scores[g].x - k99;
-        const double w0 = w[g];
-        w[g] = w0 * a * a / n_match;
-        const double l = (w0 > 0.0 && a != 0.0) ? (log(w0) + 2.0 * log(fabs(a)) - logn)
-                                                  : -INFINITY;
-        scratch[g] = l;
-        lmax = fmax(lmax, l);
-    }
-    lmax = block_max(lmax, sh);
-    double se = 0;
-    for (int g = tid; g < Pg; g += WG) se += exp(scratch[g] - lmax);
-    se = block_sum(se, sh);
-    const double lse = lmax + log(se);
-    for (int g = tid; g < Pg; g += WG) logw[g] = (float)(scratch[g] - lse);
-
-    // S3P:929: sum of the raw weights.
-    double total;
-    if (exact) {
-        total = seq_sum(w, Pg, tile, sh);
-    } else {
-        double part = 0;
-        for (int g = tid; g < Pg; g += WG) part += w[g];
-        total = block_sum(part, sh);
-    }
-    // S3P:935-937 normalise, then S3P:763-767 prefix sums.
-    __syncthreads();
-    for (int g = tid; g < Pg; g += WG) w[g] = w[g] / total;
-    __syncthreads();
-    if (exact) seq_cdf(w, Pg, cdf, tile); else par_cdf(w, Pg, cdf, tile);
-}
-
-__global__ __launch_bounds__(WG) void k_cdf_exact(const double* w, int Pg, double* cdf) {
-    __shared__ double tile[TILE];
-    seq_cdf(w, Pg, cdf, tile);
-}
-
-hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
-                       double* cdf, double* scratch, bool exact) {
-    hipLaunchKernelGGL(k_weights, dim3(1), dim3(WG), 0, st, scores, Pg, w, logw, cdf, scratch,
-                       exact ? 1 : 0);
-    return hipGetLastError();
-}
-hipError_t pfk_cdf_exact(hipStream_t st, const double* w, int Pg, double* cdf) {
-    hipLaunchKernelGGL(k_cdf_exact, dim3(1), dim3(WG), 0, st, w, Pg, cdf);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// K4 resample: S3P:757-821.
-// ------------------------------------------------------------------------------------------
-// S3P:772-780 as a binary search. For a non-decreasing CDF the reference's first j with
-// cdf[j-1] < u < cdf[j] can only be j* = first j with cdf[j] > u, and it matches iff
-// cdf[j*-1] != u. No match (boundary hit, u above the last boundary, u == 0, NaN): the draw
-// keeps its own index and is counted.
-__global__ __launch_bounds__(256) void k_search(const double* __restrict__ cdf,
-                                                const double* __restrict__ u, int Pg, double bound,
-                                                int32_t* __restrict__ draw,
-                                                unsigned long long* counters) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= Pg) return;
-    const double ui = u[i];
-    int lo = 1, hi = Pg + 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (cdf[mid] > ui) hi = mid; else lo = mid + 1;
-    }
-    const bool hit = lo <= Pg && cdf[lo - 1] < ui;
-    draw[i] = hit ? lo - 1 : i;
-    if (!hit) atomicAdd(&counters[0], 1ull);
-    if (bound > 0.0) {
-        bool amb = !hit;
-        if (hit) amb = (ui - cdf[lo - 1] <= bound) || (cdf[lo] - ui <= bound);
-        if (amb) atomicAdd(&counters[1], 1ull);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_first(const int32_t* __restrict__ draw, int Pg,
-                                               int32_t* first) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < Pg) atomicMin(&first[draw[i]], i);
-}
-
-// S3P:782-802 in parallel form. A draw is a duplicate when its ancestor was drawn earlier
-// (first[a] != i); slot j is free when nobody drew it. The k-th duplicate (draw order) goes to
-// the k-th free slot (ascending); drawn slots keep themselves.
-__global__ __launch_bounds__(WG) void k_assign(const int32_t* __restrict__ draw, int Pg,
-                                               const int32_t* __restrict__ first,
-                                               int32_t* dup_anc, int32_t* free_slot,
-                                               int32_t* __restrict__ slot_anc) {
-    __shared__ int sd[WG], sf[WG];
-    const int tid = threadIdx.x;
-    const int seg = (Pg + WG - 1) / WG;
-    const int b = tid * seg, e = min(Pg, b + seg);
-    int nd = 0, nf = 0;
-    for (int k = b; k < e; ++k) {
-        nd += first[draw[k]] != k;
-        nf += first[k] == NEVER_DRAWN;
-    }
-    sd[tid] = nd; sf[tid] = nf;
-    __syncthreads();
-    for (int o = 1; o < WG; o <<= 1) {
-        const int ad = tid >= o ? sd[tid - o] : 0, af = tid >= o ? sf[tid - o] : 0;
-        __syncthreads();
-        sd[tid] += ad; sf[tid] += af;
-        __syncthreads();
-    }
-    int rd = tid ? sd[tid - 1] : 0, rf = tid ? sf[tid - 1] : 0;
-    for (int k = b; k < e; ++k) {
-        if (first[draw[k]] != k) dup_anc[rd++] = draw[k];
-        if (first[k] == NEVER_DRAWN) free_slot[rf++] = k; else slot_anc[k] = k;
-    }
-    __syncthreads();
-    __threadfence_block();
-    const int ndup = sd[WG - 1];
-    for (int k = tid; k < ndup; k += WG) slot_anc[free_slot[k]] = dup_anc[k];
-}
-
-// S3P:805-812. Sources are slots that keep themselves, so the in-place parallel copy reads
-// nothing that this launch writes.
-__global__ __launch_bounds__(256) void k_apply_w(const int32_t* __restrict__ slot_anc, int Pg,
-                                                 double* w, float* logw) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= Pg) return;
-    const int a = slot_anc[g];
-    if (a != g) { w[g] = w[a]; logw[g] = logw[a]; }
-}
-__global__ __launch_bounds__(256) void k_apply_pose(const int32_t* __restrict__ slot_anc, int P,
-                                                    int offset, double* pose,
-                                                    const double* __restrict__ gathered) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const int g = offset + i;
-    const int a = slot_anc[g];
-    if (a == g) return;
-    if (gathered) {
-        const int r = a / P, ai = a - r * P;
-        const double* src = gathered + (size_t)r * PF_POSE_ROWS * P;
-#pragma unroll
-        for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * P + i] = src[(size_t)k * P + ai];
-    } else {
-        const int ai = a - offset;
-#pragma unroll
-        for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * P + i] = pose[(size_t)k * P + ai];
-    }
-}
-// Per-particle map slabs (S3P:810 copies the 7.2 MB map with the struct): 16 B per lane.
-__global__ __launch_bounds__(256) void k_apply_maps(const int32_t* __restrict__ slot_anc, int P,
-                                                    int offset, uint8_t* maps,
-                                                    unsigned long long stride,
-                                                    unsigned long long bytes) {
-    const int i = blockIdx.x;
-    const int a = slot_anc[offset + i];
-    if (a == offset + i) return;
-    const uint4* src = (const uint4*)(maps + stride * (unsigned long long)(a - offset));
-    uint4* dst = (uint4*)(maps + stride * (unsigned long long)i);
-    const unsigned long long n16 = (bytes + 15) / 16;        // slabs are padded to 256 B
-    for (unsigned long long k = (unsigned long long)blockIdx.y * 256 + threadIdx.x; k < n16;
-         k += (unsigned long long)gridDim.y * 256)
-        dst[k] = src[k];
-}
-
-// S3P:814-820: first index of the strict maximum above 0; otherwise the previous index stays.
-__global__ __launch_bounds__(WG) void k_argmax(const double* __restrict__ w, int Pg,
-                                               int32_t* best_inout) {
-    __shared__ double sv[WG];
-    __shared__ int si[WG];
-    const int tid = threadIdx.x;
-    double bv = 0.0; int bi = -1;
-    for (int g = tid; g < Pg; g += WG) {
-        const double v = w[g];
-        if (v > bv) { bv = v; bi = g; }          // ascending g per thread: first max kept
-    }
-    sv[tid] = bv; si[tid] = bi;
-    __syncthreads();
-    for (int o = WG / 2; o > 0; o >>= 1) {
-        if (tid < o) {
-            const double ov = sv[tid + o]; const int oi = si[tid + o];
-            if (oi >= 0 && (si[tid] < 0 || ov > sv[tid] || (ov == sv[tid] && oi < si[tid]))) {
-                sv[tid] = ov; si[tid] = oi;
-            }
-        }
-        __syncthreads();
-    }
-    if (tid == 0 && si[0] >= 0) *best_inout = si[0];
-}
-
-hipError_t pfk_search(hipStream_t st, const double* cdf, const double* u, int Pg, double bound,
-                      int32_t* draw, unsigned long long* counters) {
-    hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_search, dim3((Pg + 255) / 256), dim3(256), 0, st, cdf, u, Pg, bound, draw,
-                       counters);
-    return hipGetLastError();
-}
-hipError_t pfk_assign(hipStream_t st, const int32_t* draw, int Pg, int32_t* first,
-                      int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc) {
-    hipError_t e = hipMemsetAsync(first, 0x7f, sizeof(int32_t) * (size_t)Pg, st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_first, dim3((Pg + 255) / 256), dim3(256), 0, st, draw, Pg, first);
-    hipLaunchKernelGGL(k_assign, dim3(1), dim3(WG), 0, st, draw, Pg, first, dup_anc, free_slot,
-                       slot_anc);
-    return hipGetLastError();
-}
-hipError_t pfk_apply(hipStream_t st, const int32_t* slot_anc, int Pg, int P, int offset, double* w,
-                     float* logw, double* pose, const double* pose_gathered, uint8_t* maps,
-                     unsigned long long map_stride, unsigned long long map_bytes) {
-    hipLaunchKernelGGL(k_apply_w, dim3((Pg + 255) / 256), dim3(256), 0, st, slot_anc, Pg, w, logw);
-    hipLaunchKernelGGL(k_apply_pose, dim3((P + 255) / 256), dim3(256), 0, st, slot_anc, P, offset,
-                       pose, pose_gathered);
-    if (maps && map_stride) {
-        unsigned long long n16 = (map_bytes + 15) / 16;
-        int gy = (int)((n16 + 256ull * 8 - 1) / (256ull * 8));
-        if (gy < 1) gy = 1;
-        if (gy > 64) gy = 64;
-        hipLaunchKernelGGL(k_apply_maps, dim3(P, gy), dim3(256), 0, st, slot_anc, P, offset, maps,
-                           map_stride, map_bytes);
-    }
-    return hipGetLastError();
-}
-hipError_t pfk_argmax(hipStream_t st, const double* w, int Pg, int32_t* best_inout) {
-    hipLaunchKernelGGL(k_argmax, dim3(1), dim3(WG), 0, st, w, Pg, best_inout);
     return hipGetLastError();
 }
 

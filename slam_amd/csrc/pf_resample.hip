@@ -1,0 +1,555 @@
+// gfx950 kernels for the weight update (K3, S3P:920-937) and the resampler (K4, S3P:757-821).
+// Built with -ffp-contract=off like pf_kernels.hip.
+//
+// Two orders of summation:
+//  EXACT  one workgroup, the raw-weight sum and the CDF are added by ONE lane in the
+//         reference's index order (tiles staged through LDS): every fp64 result is bit-identical
+//         to the sequential CPU loop. Used for n_particles_global <= 2048 (PF_ORDER_AUTO) or
+//         on request.
+//  FAST   multi-workgroup, fixed-shape reductions and scans (the shape depends only on the
+//         particle count, never on the grid or the GPU, so every rank that runs this redundantly
+//         gets bit-identical results). The sums differ from the sequential ones by rounding
+//         only; k_search counts the draws that fall within that error of a CDF boundary and
+//         the host re-settles them on the sequential-order CDF (k_cdf_exact_if).
+#include "pf_kernels.h"
+#include <limits.h>
+#include <math.h>
+
+#define WAVE 64
+#define WG 1024
+#define TILE 4096
+#define NB 256                   // threads per block of the multi-block kernels
+#define NEVER_DRAWN 0x7f7f7f7f   // hipMemsetAsync(first, 0x7f): larger than any slot number
+
+// prm[] layout (device doubles)
+#define PRM_K99 0      // 0.99 * smallest sum (S3P:928)
+#define PRM_N 1        // num_match of the last particle
+#define PRM_S 2        // sum of the raw weights (S3P:929)
+#define PRM_LSE 3      // log-sum-exp of the log-domain raw weights
+#define PRM_LOGN 4
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+    return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, WAVE));
+    return v;
+}
+__device__ inline int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_down(v, o, WAVE));
+    return v;
+}
+// Block-wide reductions; result broadcast to every thread. sh: blockDim/64 doubles. The wave
+// totals are added in wave order by every thread: one fixed shape.
+__device__ inline double block_sum(double v, double* sh) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    double r = 0;
+    for (int k = 0; k < nw; ++k) r += sh[k];
+    return r;
+}
+__device__ inline double block_max(double v, double* sh) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    double r = sh[0];
+    for (int k = 1; k < nw; ++k) r = fmax(r, sh[k]);
+    return r;
+}
+// Inclusive wave scan (Kogge-Stone over the 64 lanes), fixed shape.
+__device__ inline double wave_scan(double v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const double t = __shfl_up(v, o, WAVE);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ inline int wave_scan_i(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int t = __shfl_up(v, o, WAVE);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Sequential-order sum of src[0..n) (S3P:929): tiles staged in LDS, one lane adds in order.
+__device__ inline double seq_sum(const double* src, int n, double* tile, double* sh) {
+    double run = 0;
+    for (int base = 0; base < n; base += TILE) {
+        const int cntv = min(TILE, n - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cntv; k += WG) tile[k] = src[base + k];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < cntv; ++k) run += tile[k];
+        }
+    }
+    if (threadIdx.x == 0) sh[0] = run;
+    __syncthreads();
+    run = sh[0];
+    __syncthreads();
+    return run;
+}
+
+// Sequential-order inclusive prefix sums (S3P:763-767): cdf[0] = 0, cdf[i+1] = cdf[i] + w[i].
+__device__ inline void seq_cdf(const double* w, int n, double* cdf, double* tile) {
+    __shared__ double carry;
+    if (threadIdx.x == 0) { carry = 0; cdf[0] = 0; }
+    for (int base = 0; base < n; base += TILE) {
+        const int cntv = min(TILE, n - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cntv; k += WG) tile[k] = w[base + k];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double run = carry;
+            for (int k = 0; k < cntv; ++k) { run += tile[k]; tile[k] = run; }
+            carry = run;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < cntv; k += WG) cdf[base + 1 + k] = tile[k];
+    }
+    __syncthreads();
+}
+
+// S3P:928 for one particle: the raw weight and its log-domain twin for the log-sum-exp.
+__device__ inline void raw_weight(double w0, int s, double k99, double n_match, double logn,
+                                  double& raw, double& l) {
+    const double a = (double)s - k99;
+    raw = w0 * a * a / n_match;
+    l = (w0 > 0.0 && a != 0.0) ? (log(w0) + 2.0 * log(fabs(a)) - logn) : -INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------
+// EXACT order: everything in one workgroup of 1024 threads.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_weights_exact(const int2* __restrict__ scores, int Pg,
+                                                      double* w, float* __restrict__ logw,
+                                                      double* cdf, double* scratch) {
+    __shared__ double tile[TILE];
+    __shared__ double sh[WG / WAVE];
+    __shared__ int shi[WG / WAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // S3P:920-925: smallest sum (ints: the order of the reduction does not matter).
+    int m = INT_MAX;
+    for (int g = tid; g < Pg; g += WG) m = min(m, scores[g].x);
+    m = wave_min_i(m);
+    if (lane == 0) shi[wv] = m;
+    __syncthreads();
+    m = shi[0];
+    for (int k = 1; k < WG / WAVE; ++k) m = min(m, shi[k]);
+    double smallest = 1000000000000.0;
+    if (smallest > (double)m) smallest = (double)m;
+    const double n_match = (double)scores[Pg - 1].y;     // S3P:865 + S3P:928: the LAST particle's
+    const double k99 = 0.99 * smallest;
+    const double logn = log(n_match);
+
+    double lmax = -INFINITY;
+    for (int g = tid; g < Pg; g += WG) {
+        double raw, l;
+        raw_weight(w[g], scores[g].x, k99, n_match, logn, raw, l);
+        w[g] = raw;
+        scratch[g] = l;
+        lmax = fmax(lmax, l);
+    }
+    lmax = block_max(lmax, sh);
+    double se = 0;
+    for (int g = tid; g < Pg; g += WG) se += exp(scratch[g] - lmax);
+    se = block_sum(se, sh);
+    const double lse = lmax + log(se);
+    for (int g = tid; g < Pg; g += WG) logw[g] = (float)(scratch[g] - lse);
+
+    const double total = seq_sum(w, Pg, tile, sh);        // S3P:929
+    __syncthreads();
+    for (int g = tid; g < Pg; g += WG) w[g] = w[g] / total;   // S3P:935-937
+    __syncthreads();
+    seq_cdf(w, Pg, cdf, tile);                            // S3P:763-767
+}
+
+// Sequential-order CDF of the current weights, only when counters[1] (ambiguous draws) != 0.
+__global__ __launch_bounds__(WG) void k_cdf_exact_if(const double* w, int Pg, double* cdf,
+                                                     const unsigned long long* counters) {
+    __shared__ double tile[TILE];
+    if (counters[1] == 0) return;
+    seq_cdf(w, Pg, cdf, tile);
+}
+
+// ------------------------------------------------------------------------------------------
+// FAST order: K3 as four kernels.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k3_min(const int2* __restrict__ scores, int Pg, double* prm) {
+    __shared__ int shi[WG / WAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int m = INT_MAX;
+    for (int g = tid; g < Pg; g += WG) m = min(m, scores[g].x);
+    m = wave_min_i(m);
+    if (lane == 0) shi[wv] = m;
+    __syncthreads();
+    if (tid == 0) {
+        m = shi[0];
+        for (int k = 1; k < WG / WAVE; ++k) m = min(m, shi[k]);
+        double smallest = 1000000000000.0;                 // S3P:920
+        if (smallest > (double)m) smallest = (double)m;
+        const double n_match = (double)scores[Pg - 1].y;
+        prm[PRM_K99] = 0.99 * smallest;
+        prm[PRM_N] = n_match;
+        prm[PRM_LOGN] = log(n_match);
+    }
+}
+
+// raw weights + per-block partials: bsum[b] = sum of the block's raw weights (wave shuffle tree,
+// then the 4 wave totals in order), (bmax[b], bse[b]) = block max of l and sum of exp(l - bmax).
+__global__ __launch_bounds__(NB) void k3_raw(const int2* __restrict__ scores, int Pg, double* w,
+                                             double* __restrict__ lbuf,
+                                             const double* __restrict__ prm, double* bsum,
+                                             double* bmax, double* bse) {
+    __shared__ double sh[NB / WAVE];
+    const int g = blockIdx.x * NB + threadIdx.x;
+    double raw = 0, l = -INFINITY;
+    if (g < Pg) {
+        raw_weight(w[g], scores[g].x, prm[PRM_K99], prm[PRM_N], prm[PRM_LOGN], raw, l);
+        w[g] = raw;
+        lbuf[g] = l;
+    }
+    const double s = block_sum(raw, sh);
+    const double m = block_max(l, sh);
+    const double e = block_sum((g < Pg && l > -INFINITY) ? exp(l - m) : 0.0, sh);
+    if (threadIdx.x == 0) { bsum[blockIdx.x] = s; bmax[blockIdx.x] = m; bse[blockIdx.x] = e; }
+}
+
+// One workgroup: S = sum of bsum (thread t adds blocks t, t+1024, ... then the fixed tree),
+// exclusive scan of bsum into boff, global max / log-sum-exp.
+__global__ __launch_bounds__(WG) void k3_combine(int nb, const double* __restrict__ bsum,
+                                                 const double* __restrict__ bmax,
+                                                 const double* __restrict__ bse, double* boff,
+                                                 double* prm) {
+    __shared__ double sh[WG / WAVE];
+    __shared__ double tile[WG];
+    const int tid = threadIdx.x;
+    // contiguous segment per thread so that the scan is a scan
+    const int seg = (nb + WG - 1) / WG;
+    const int b = tid * seg, e = min(nb, b + seg);
+    double local = 0, m = -INFINITY;
+    for (int k = b; k < e; ++k) { local += bsum[k]; m = fmax(m, bmax[k]); }
+    // exclusive scan of the thread totals: wave scan + wave offsets (fixed shape)
+    const double inc = wave_scan(local);
+    const int lane = tid & 63, wv = tid >> 6;
+    __syncthreads();
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    double woff = 0;
+    for (int k = 0; k < wv; ++k) woff += sh[k];
+    double total = 0;
+    for (int k = 0; k < WG / WAVE; ++k) total += sh[k];
+    double run = woff + inc - local;
+    for (int k = b; k < e; ++k) { boff[k] = run; run += bsum[k]; }
+    const double gmax = block_max(m, sh);
+    double se = 0;
+    for (int k = b; k < e; ++k) se += bmax[k] > -INFINITY ? bse[k] * exp(bmax[k] - gmax) : 0.0;
+    se = block_sum(se, sh);
+    (void)tile;
+    if (tid == 0) {
+        prm[PRM_S] = total;
+        prm[PRM_LSE] = gmax + log(se);
+    }
+}
+
+// normalise, log-weights, CDF: cdf[i+1] = (boff[block] + inclusive scan of raw inside the block) / S.
+__global__ __launch_bounds__(NB) void k3_norm(int Pg, double* w, const double* __restrict__ lbuf,
+                                              float* __restrict__ logw,
+                                              const double* __restrict__ prm,
+                                              const double* __restrict__ boff, double* cdf) {
+    __shared__ double sh[NB / WAVE];
+    const int g = blockIdx.x * NB + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double S = prm[PRM_S];
+    const double raw = g < Pg ? w[g] : 0.0;
+    const double inc = wave_scan(raw);
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    double woff = 0;
+    for (int k = 0; k < wv; ++k) woff += sh[k];
+    if (g < Pg) {
+        w[g] = raw / S;                                     // S3P:936
+        logw[g] = (float)(lbuf[g] - prm[PRM_LSE]);
+        cdf[g + 1] = (boff[blockIdx.x] + (woff + inc)) / S;
+    }
+    if (g == 0) cdf[0] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4 resample: S3P:757-821.
+// ------------------------------------------------------------------------------------------
+// S3P:772-780 as a binary search. For a non-decreasing CDF the reference's first j with
+// cdf[j-1] < u < cdf[j] can only be j* = first j with cdf[j] > u, and it matches iff
+// cdf[j*-1] != u. No match (boundary hit, u above the last boundary, u == 0, NaN): the draw
+// keeps its own index and is counted. only_if_ambiguous: the re-search after k_cdf_exact_if.
+__global__ __launch_bounds__(NB) void k_search(const double* __restrict__ cdf,
+                                               const double* __restrict__ u, int Pg, double bound,
+                                               int32_t* __restrict__ draw,
+                                               unsigned long long* counters, int only_if_ambiguous) {
+    if (only_if_ambiguous && counters[1] == 0) return;
+    const int i = blockIdx.x * NB + threadIdx.x;
+    if (i >= Pg) return;
+    const double ui = u[i];
+    int lo = 1, hi = Pg + 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] > ui) hi = mid; else lo = mid + 1;
+    }
+    const bool hit = lo <= Pg && cdf[lo - 1] < ui;
+    draw[i] = hit ? lo - 1 : i;
+    if (only_if_ambiguous) {
+        // counters[0] was counted on the parallel CDF; recount on the sequential one
+        if (!hit) atomicAdd(&counters[2], 1ull);
+        return;
+    }
+    if (!hit) atomicAdd(&counters[0], 1ull);
+    if (bound > 0.0) {
+        bool amb = !hit;
+        if (hit) amb = (ui - cdf[lo - 1] <= bound) || (cdf[lo] - ui <= bound);
+        if (amb) atomicAdd(&counters[1], 1ull);
+    }
+}
+
+__global__ __launch_bounds__(NB) void k_first(const int32_t* __restrict__ draw, int Pg,
+                                              int32_t* first) {
+    const int i = blockIdx.x * NB + threadIdx.x;
+    if (i < Pg) atomicMin(&first[draw[i]], i);
+}
+
+// S3P:782-802 in parallel form. A draw is a duplicate when its ancestor was drawn earlier
+// (first[a] != i); slot j is free when nobody drew it. The k-th duplicate (draw order) goes to
+// the k-th free slot (ascending); drawn slots keep themselves. Three kernels: per-block counts,
+// scan of the counts, ranked scatter; then the fill.
+__global__ __launch_bounds__(NB) void k4_count(const int32_t* __restrict__ draw, int Pg,
+                                               const int32_t* __restrict__ first, int2* bcnt) {
+    __shared__ int sd[NB / WAVE], sf[NB / WAVE];
+    const int i = blockIdx.x * NB + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int isd = i < Pg && first[draw[i]] != i;
+    const int isf = i < Pg && first[i] == NEVER_DRAWN;
+    const int nd = __popcll(__ballot(isd)), nf = __popcll(__ballot(isf));
+    if (lane == 0) { sd[wv] = nd; sf[wv] = nf; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0;
+        for (int k = 0; k < NB / WAVE; ++k) { a += sd[k]; b += sf[k]; }
+        bcnt[blockIdx.x] = make_int2(a, b);
+    }
+}
+__global__ __launch_bounds__(WG) void k4_scan(int nb, const int2* __restrict__ bcnt, int2* boff,
+                                              int32_t* ndup_out) {
+    __shared__ int sd[WG / WAVE], sf[WG / WAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int seg = (nb + WG - 1) / WG;
+    const int b = tid * seg, e = min(nb, b + seg);
+    int ld = 0, lf = 0;
+    for (int k = b; k < e; ++k) { ld += bcnt[k].x; lf += bcnt[k].y; }
+    const int id = wave_scan_i(ld), jf = wave_scan_i(lf);
+    if (lane == 63) { sd[wv] = id; sf[wv] = jf; }
+    __syncthreads();
+    int od = 0, of = 0;
+    for (int k = 0; k < wv; ++k) { od += sd[k]; of += sf[k]; }
+    int rd = od + id - ld, rf = of + jf - lf;
+    for (int k = b; k < e; ++k) { boff[k] = make_int2(rd, rf); rd += bcnt[k].x; rf += bcnt[k].y; }
+    if (tid == WG - 1) *ndup_out = od + id;
+}
+__global__ __launch_bounds__(NB) void k4_scatter(const int32_t* __restrict__ draw, int Pg,
+                                                 const int32_t* __restrict__ first,
+                                                 const int2* __restrict__ boff,
+                                                 int32_t* __restrict__ dup_anc,
+                                                 int32_t* __restrict__ free_slot,
+                                                 int32_t* __restrict__ slot_anc) {
+    __shared__ int sd[NB / WAVE], sf[NB / WAVE];
+    const int i = blockIdx.x * NB + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int a = i < Pg ? draw[i] : 0;
+    const int isd = i < Pg && first[a] != i;
+    const int isf = i < Pg && first[i] == NEVER_DRAWN;
+    const unsigned long long md = __ballot(isd), mf = __ballot(isf);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) { sd[wv] = __popcll(md); sf[wv] = __popcll(mf); }
+    __syncthreads();
+    int od = boff[blockIdx.x].x, of = boff[blockIdx.x].y;
+    for (int k = 0; k < wv; ++k) { od += sd[k]; of += sf[k]; }
+    if (isd) dup_anc[od + __popcll(md & below)] = a;
+    if (isf) free_slot[of + __popcll(mf & below)] = i;
+    else if (i < Pg) slot_anc[i] = i;
+}
+__global__ __launch_bounds__(NB) void k4_fill(const int32_t* __restrict__ ndup,
+                                              const int32_t* __restrict__ dup_anc,
+                                              const int32_t* __restrict__ free_slot,
+                                              int32_t* __restrict__ slot_anc) {
+    const int n = *ndup;
+    for (int k = blockIdx.x * NB + threadIdx.x; k < n; k += gridDim.x * NB)
+        slot_anc[free_slot[k]] = dup_anc[k];
+}
+
+// S3P:805-812 + the first stage of S3P:814-820. Sources are slots that keep themselves, so the
+// in-place parallel copy reads nothing that this launch writes. Per block: the first index of
+// the block's strict maximum of the NEW weights above 0.
+__global__ __launch_bounds__(NB) void k4_apply_w(const int32_t* __restrict__ slot_anc, int Pg,
+                                                 double* w, float* logw, double* bbest_v,
+                                                 int32_t* bbest_i) {
+    __shared__ double sv[NB / WAVE];
+    __shared__ int si[NB / WAVE];
+    const int g = blockIdx.x * NB + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double v = 0.0;
+    int idx = -1;
+    if (g < Pg) {
+        const int a = slot_anc[g];
+        v = w[a];
+        if (a != g) { w[g] = v; logw[g] = logw[a]; }
+        if (v > 0.0) idx = g; else v = 0.0;                 // NaN and <= 0 never win (S3P:816)
+    }
+    // wave arg-max: larger value wins, ties go to the lower index
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_down(v, o, WAVE);
+        const int oi = __shfl_down(idx, o, WAVE);
+        if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+    }
+    if (lane == 0) { sv[wv] = v; si[wv] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < NB / WAVE; ++k)
+            if (si[k] >= 0 && (idx < 0 || sv[k] > v || (sv[k] == v && si[k] < idx))) { v = sv[k]; idx = si[k]; }
+        bbest_v[blockIdx.x] = v;
+        bbest_i[blockIdx.x] = idx;
+    }
+}
+__global__ __launch_bounds__(WG) void k4_argmax(int nb, const double* __restrict__ bbest_v,
+                                                const int32_t* __restrict__ bbest_i,
+                                                int32_t* best_inout) {
+    __shared__ double sv[WG];
+    __shared__ int si[WG];
+    const int tid = threadIdx.x;
+    double v = 0.0; int idx = -1;
+    for (int k = tid; k < nb; k += WG) {
+        const int oi = bbest_i[k]; const double ov = bbest_v[k];
+        if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+    }
+    sv[tid] = v; si[tid] = idx;
+    __syncthreads();
+    for (int o = WG / 2; o > 0; o >>= 1) {
+        if (tid < o) {
+            const double ov = sv[tid + o]; const int oi = si[tid + o];
+            if (oi >= 0 && (si[tid] < 0 || ov > sv[tid] || (ov == sv[tid] && oi < si[tid]))) {
+                sv[tid] = ov; si[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && si[0] >= 0) *best_inout = si[0];        // otherwise the previous index stays
+}
+
+__global__ __launch_bounds__(NB) void k_apply_pose(const int32_t* __restrict__ slot_anc, int P,
+                                                   int offset, double* pose,
+                                                   const double* __restrict__ gathered) {
+    const int i = blockIdx.x * NB + threadIdx.x;
+    if (i >= P) return;
+    const int g = offset + i;
+    const int a = slot_anc[g];
+    if (a == g) return;
+    if (gathered) {
+        const int r = a / P, ai = a - r * P;
+        const double* src = gathered + (size_t)r * PF_POSE_ROWS * P;
+#pragma unroll
+        for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * P + i] = src[(size_t)k * P + ai];
+    } else {
+        const int ai = a - offset;
+#pragma unroll
+        for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * P + i] = pose[(size_t)k * P + ai];
+    }
+}
+// Per-particle map slabs (S3P:810 copies the 7.2 MB map with the struct): 16 B per lane.
+__global__ __launch_bounds__(NB) void k_apply_maps(const int32_t* __restrict__ slot_anc, int P,
+                                                   int offset, uint8_t* maps,
+                                                   unsigned long long stride,
+                                                   unsigned long long bytes) {
+    const int i = blockIdx.x;
+    const int a = slot_anc[offset + i];
+    if (a == offset + i) return;
+    const uint4* src = (const uint4*)(maps + stride * (unsigned long long)(a - offset));
+    uint4* dst = (uint4*)(maps + stride * (unsigned long long)i);
+    const unsigned long long n16 = (bytes + 15) / 16;        // slabs are padded to 256 B
+    for (unsigned long long k = (unsigned long long)blockIdx.y * NB + threadIdx.x; k < n16;
+         k += (unsigned long long)gridDim.y * NB)
+        dst[k] = src[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline int nblocks(int n) { return (n + NB - 1) / NB; }
+
+hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
+                       double* cdf, double* scratch, bool exact, PfResampleScratch sc) {
+    if (exact) {
+        hipLaunchKernelGGL(k_weights_exact, dim3(1), dim3(WG), 0, st, scores, Pg, w, logw, cdf, scratch);
+        return hipGetLastError();
+    }
+    const int nb = nblocks(Pg);
+    hipLaunchKernelGGL(k3_min, dim3(1), dim3(WG), 0, st, scores, Pg, sc.prm);
+    hipLaunchKernelGGL(k3_raw, dim3(nb), dim3(NB), 0, st, scores, Pg, w, scratch, sc.prm, sc.bsum,
+                       sc.bmax, sc.bse);
+    hipLaunchKernelGGL(k3_combine, dim3(1), dim3(WG), 0, st, nb, sc.bsum, sc.bmax, sc.bse, sc.boff, sc.prm);
+    hipLaunchKernelGGL(k3_norm, dim3(nb), dim3(NB), 0, st, Pg, w, scratch, logw, sc.prm, sc.boff, cdf);
+    return hipGetLastError();
+}
+
+// counters: unsigned long long [3] = {nohit, ambiguous, nohit after the re-search}.
+hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int Pg, int P,
+                        int offset, double bound, double* w, float* logw, double* pose,
+                        const double* pose_gathered, uint8_t* maps, unsigned long long map_stride,
+                        unsigned long long map_bytes, int32_t* draw, int32_t* first,
+                        int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
+                        unsigned long long* counters, PfResampleScratch sc) {
+    const int nb = nblocks(Pg);
+    hipError_t e = hipMemsetAsync(counters, 0, 3 * sizeof(unsigned long long), st);   // [3] holds best
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(first, 0x7f, sizeof(int32_t) * (size_t)Pg, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, bound, draw, counters, 0);
+    if (bound > 0.0) {
+        // settle draws that sit within the parallel CDF's rounding error of a boundary on the
+        // sequential-order CDF of the same weights (both kernels return at once when there are none)
+        hipLaunchKernelGGL(k_cdf_exact_if, dim3(1), dim3(WG), 0, st, w, Pg, (double*)cdf, counters);
+        hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, 0.0, draw, counters, 1);
+    }
+    hipLaunchKernelGGL(k_first, dim3(nb), dim3(NB), 0, st, draw, Pg, first);
+    hipLaunchKernelGGL(k4_count, dim3(nb), dim3(NB), 0, st, draw, Pg, first, sc.bcnt);
+    hipLaunchKernelGGL(k4_scan, dim3(1), dim3(WG), 0, st, nb, sc.bcnt, sc.boff2, sc.ndup);
+    hipLaunchKernelGGL(k4_scatter, dim3(nb), dim3(NB), 0, st, draw, Pg, first, sc.boff2, dup_anc,
+                       free_slot, slot_anc);
+    hipLaunchKernelGGL(k4_fill, dim3(nb < 64 ? nb : 64), dim3(NB), 0, st, sc.ndup, dup_anc, free_slot,
+                       slot_anc);
+    hipLaunchKernelGGL(k4_apply_w, dim3(nb), dim3(NB), 0, st, slot_anc, Pg, w, logw, sc.bbest_v, sc.bbest_i);
+    hipLaunchKernelGGL(k_apply_pose, dim3(nblocks(P)), dim3(NB), 0, st, slot_anc, P, offset, pose,
+                       pose_gathered);
+    if (maps && map_stride) {
+        unsigned long long n16 = (map_bytes + 15) / 16;
+        int gy = (int)((n16 + 256ull * 8 - 1) / (256ull * 8));
+        if (gy < 1) gy = 1;
+        if (gy > 64) gy = 64;
+        hipLaunchKernelGGL(k_apply_maps, dim3(P, gy), dim3(NB), 0, st, slot_anc, P, offset, maps,
+                           map_stride, map_bytes);
+    }
+    hipLaunchKernelGGL(k4_argmax, dim3(1), dim3(WG), 0, st, nb, sc.bbest_v, sc.bbest_i, best);
+    return hipGetLastError();
+}

@@ -367,3 +367,32 @@ def test_full_size_properties_c2():
         assert np.array_equal(slots, sa) and obest == best
     finally:
         h.close()
+
+
+def test_predict_device_equals_predict():
+    """pf_predict_device hands over a pose block that already lives in HBM (the bench's path):
+    same scores, weights and slots as the host upload of the same poses."""
+    import torch
+    P, M, dims = 3000, 600, (96, 96, 64)
+    sc = synth.scene(dims, P, M, seed=21)
+    u = capi.draw_uniform(77, P)
+    res = []
+    for mode in ("host", "device"):
+        h = capi.Handle(_shared_cfg(P, dims))
+        try:
+            h.write_map(0, sc["grid"]); h.set_beams(*sc["beams"])
+            if mode == "host":
+                h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+            else:
+                src = capi.Handle(_shared_cfg(P, dims))
+                src.predict(sc["x"], sc["y"], sc["z"], sc["yaw"]); src.synchronize()
+                blk = src.poses_tensor().clone(); torch.cuda.synchronize()
+                src.close()
+                h.predict_device(blk.data_ptr())
+            h.measure(0); s, c = h.get_scores(); h.weights(); w, lw = h.get_weights()
+            slots, best, nohit, amb = h.resample(u)
+            res.append((s, c, w, slots, best, nohit, np.stack(h.get_poses())))
+        finally:
+            h.close()
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)

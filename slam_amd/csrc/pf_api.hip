@@ -571,7 +571,8 @@ int pf_weights(pf_handle* h, const void* scores_global_dev) {
     const int2* sc = scores_global_dev ? (const int2*)scores_global_dev : h->scores;
     {
         Timed t(h, PF_K_WEIGHTS);
-        HIP_TRY(h, pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact, h->rs));
+        HIP_TRY(h, pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact, h->first,
+                               h->counters, h->rs));
     }
     h->weighted = true;
     return PF_OK;

@@ -68,8 +68,10 @@ struct PfResampleScratch {
 };
 
 // K3: S3P:920-937. w in/out [Pg]; logw out [Pg]; cdf out [Pg+1]; scratch double [Pg+1].
+// Also initialises K4's first[Pg] table and counters[0..2] for this step.
 hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
-                       double* cdf, double* scratch, bool exact, PfResampleScratch sc);
+                       double* cdf, double* scratch, bool exact, int32_t* first,
+                       unsigned long long* counters, PfResampleScratch sc);
 
 // K4: S3P:757-821, the whole chain on the stream, no host round trip: search (+ re-search of
 // ambiguous draws on the sequential-order CDF when bound > 0), slot assignment, permutation of

@@ -266,26 +266,35 @@ __global__ __launch_bounds__(256) void k_order_hist(const double* __restrict__ p
     keys[i] = k;
     atomicAdd(&hist[k], 1);
 }
-// exclusive scan of hist in place; zeroes the buffer the NEXT sort will count into
+// exclusive scan of hist in place; zeroes the buffer the NEXT sort will count into.
+// One workgroup of 16 waves; wave w owns the contiguous segment [w*2048, (w+1)*2048) and walks
+// it 64 entries at a time (coalesced), so the scan is 2 x 32 wave-iterations, not a per-thread
+// strided walk.
 __global__ __launch_bounds__(1024) void k_order_scan(int32_t* hist, int32_t* next_hist) {
-    __shared__ int sh[1024];
-    const int tid = threadIdx.x;
-    const int per = ORDER_BUCKETS / 1024;
-    int local[ORDER_BUCKETS / 1024];
-    int tot = 0;
+    __shared__ int tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int seg = ORDER_BUCKETS / 16;
+    int32_t* h = hist + wv * seg;
+    int sum = 0;
+    for (int k = lane; k < seg; k += 64) sum += h[k];
 #pragma unroll
-    for (int k = 0; k < per; ++k) { local[k] = hist[tid * per + k]; tot += local[k]; }
-    sh[tid] = tot;
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) tot[wv] = sum;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int add = tid >= o ? sh[tid - o] : 0;
-        __syncthreads();
-        sh[tid] += add;
-        __syncthreads();
-    }
-    int run = tid ? sh[tid - 1] : 0;
+    int carry = 0;
+    for (int k = 0; k < wv; ++k) carry += tot[k];
+    for (int k = lane; k < seg; k += 64) {
+        const int v = h[k];
+        int inc = v;
 #pragma unroll
-    for (int k = 0; k < per; ++k) { hist[tid * per + k] = run; run += local[k]; next_hist[tid * per + k] = 0; }
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        h[k] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+        next_hist[wv * seg + k] = 0;
+    }
 }
 __global__ __launch_bounds__(256) void k_order_scatter(const int32_t* __restrict__ keys, int P,
                                                        int32_t* hist, int32_t* __restrict__ order) {

@@ -19,7 +19,7 @@
 #define WG 1024
 #define TILE 4096
 #define NB 256                   // threads per block of the multi-block kernels
-#define NEVER_DRAWN 0x7f7f7f7f   // hipMemsetAsync(first, 0x7f): larger than any slot number
+#define NEVER_DRAWN 0x7f7f7f7f   // "nobody drew this slot": larger than any slot number
 
 // prm[] layout (device doubles)
 #define PRM_K99 0      // 0.99 * smallest sum (S3P:928)
@@ -137,7 +137,9 @@ __device__ inline void raw_weight(double w0, int s, double k99, double n_match, 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_weights_exact(const int2* __restrict__ scores, int Pg,
                                                       double* w, float* __restrict__ logw,
-                                                      double* cdf, double* scratch) {
+                                                      double* cdf, double* scratch,
+                                                      int32_t* __restrict__ first,
+                                                      unsigned long long* counters) {
     __shared__ double tile[TILE];
     __shared__ double sh[WG / WAVE];
     __shared__ int shi[WG / WAVE];
@@ -170,7 +172,8 @@ __global__ __launch_bounds__(WG) void k_weights_exact(const int2* __restrict__ s
     for (int g = tid; g < Pg; g += WG) se += exp(scratch[g] - lmax);
     se = block_sum(se, sh);
     const double lse = lmax + log(se);
-    for (int g = tid; g < Pg; g += WG) logw[g] = (float)(scratch[g] - lse);
+    for (int g = tid; g < Pg; g += WG) { logw[g] = (float)(scratch[g] - lse); first[g] = NEVER_DRAWN; }
+    if (tid < 3) counters[tid] = 0;                       // K4's counters start at zero
 
     const double total = seq_sum(w, Pg, tile, sh);        // S3P:929
     __syncthreads();
@@ -271,7 +274,9 @@ __global__ __launch_bounds__(WG) void k3_combine(int nb, const double* __restric
 __global__ __launch_bounds__(NB) void k3_norm(int Pg, double* w, const double* __restrict__ lbuf,
                                               float* __restrict__ logw,
                                               const double* __restrict__ prm,
-                                              const double* __restrict__ boff, double* cdf) {
+                                              const double* __restrict__ boff, double* cdf,
+                                              int32_t* __restrict__ first,
+                                              unsigned long long* counters) {
     __shared__ double sh[NB / WAVE];
     const int g = blockIdx.x * NB + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -286,8 +291,10 @@ __global__ __launch_bounds__(NB) void k3_norm(int Pg, double* w, const double* _
         w[g] = raw / S;                                     // S3P:936
         logw[g] = (float)(lbuf[g] - prm[PRM_LSE]);
         cdf[g + 1] = (boff[blockIdx.x] + (woff + inc)) / S;
+        first[g] = NEVER_DRAWN;                             // K4's first-occurrence table
     }
     if (g == 0) cdf[0] = 0;
+    if (g < 3) counters[g] = 0;                             // K4's counters start at zero
 }
 
 // ------------------------------------------------------------------------------------------
@@ -296,27 +303,27 @@ __global__ __launch_bounds__(NB) void k3_norm(int Pg, double* w, const double* _
 // S3P:772-780 as a binary search. For a non-decreasing CDF the reference's first j with
 // cdf[j-1] < u < cdf[j] can only be j* = first j with cdf[j] > u, and it matches iff
 // cdf[j*-1] != u. No match (boundary hit, u above the last boundary, u == 0, NaN): the draw
-// keeps its own index and is counted. only_if_ambiguous: the re-search after k_cdf_exact_if.
-__global__ __launch_bounds__(NB) void k_search(const double* __restrict__ cdf,
-                                               const double* __restrict__ u, int Pg, double bound,
-                                               int32_t* __restrict__ draw,
-                                               unsigned long long* counters, int only_if_ambiguous) {
-    if (only_if_ambiguous && counters[1] == 0) return;
-    const int i = blockIdx.x * NB + threadIdx.x;
-    if (i >= Pg) return;
-    const double ui = u[i];
+// keeps its own index and is counted.
+__device__ inline int search_draw(const double* __restrict__ cdf, double ui, int i, int Pg,
+                                  bool& hit, int& pos) {
     int lo = 1, hi = Pg + 1;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (cdf[mid] > ui) hi = mid; else lo = mid + 1;
     }
-    const bool hit = lo <= Pg && cdf[lo - 1] < ui;
-    draw[i] = hit ? lo - 1 : i;
-    if (only_if_ambiguous) {
-        // counters[0] was counted on the parallel CDF; recount on the sequential one
-        if (!hit) atomicAdd(&counters[2], 1ull);
-        return;
-    }
+    hit = lo <= Pg && cdf[lo - 1] < ui;
+    pos = lo;
+    return hit ? lo - 1 : i;
+}
+__global__ __launch_bounds__(NB) void k_search(const double* __restrict__ cdf,
+                                               const double* __restrict__ u, int Pg, double bound,
+                                               int32_t* __restrict__ draw,
+                                               unsigned long long* counters) {
+    const int i = blockIdx.x * NB + threadIdx.x;
+    if (i >= Pg) return;
+    const double ui = u[i];
+    bool hit; int lo;
+    draw[i] = search_draw(cdf, ui, i, Pg, hit, lo);
     if (!hit) atomicAdd(&counters[0], 1ull);
     if (bound > 0.0) {
         bool amb = !hit;
@@ -325,10 +332,22 @@ __global__ __launch_bounds__(NB) void k_search(const double* __restrict__ cdf,
     }
 }
 
-__global__ __launch_bounds__(NB) void k_first(const int32_t* __restrict__ draw, int Pg,
-                                              int32_t* first) {
+// first[a] = position of the first draw of ancestor a. When the FAST-order search flagged
+// ambiguous draws, k_cdf_exact_if has rebuilt the CDF in sequential order in between and every
+// draw is searched again here (no-hits recounted in counters[2]).
+__global__ __launch_bounds__(NB) void k_first(const double* __restrict__ cdf,
+                                              const double* __restrict__ u, int32_t* draw, int Pg,
+                                              int32_t* first, unsigned long long* counters) {
     const int i = blockIdx.x * NB + threadIdx.x;
-    if (i < Pg) atomicMin(&first[draw[i]], i);
+    if (i >= Pg) return;
+    int a = draw[i];
+    if (counters[1] != 0) {
+        bool hit; int lo;
+        a = search_draw(cdf, u[i], i, Pg, hit, lo);
+        draw[i] = a;
+        if (!hit) atomicAdd(&counters[2], 1ull);
+    }
+    atomicMin(&first[a], i);
 }
 
 // S3P:782-802 in parallel form. A draw is a duplicate when its ancestor was drawn earlier
@@ -387,24 +406,19 @@ __global__ __launch_bounds__(NB) void k4_scatter(const int32_t* __restrict__ dra
     int od = boff[blockIdx.x].x, of = boff[blockIdx.x].y;
     for (int k = 0; k < wv; ++k) { od += sd[k]; of += sf[k]; }
     if (isd) dup_anc[od + __popcll(md & below)] = a;
-    if (isf) free_slot[of + __popcll(mf & below)] = i;
+    // a free slot takes the duplicate of its own rank; k4_apply resolves -1-rank -> dup_anc[rank]
+    if (isf) slot_anc[i] = -1 - (of + __popcll(mf & below));
     else if (i < Pg) slot_anc[i] = i;
 }
-__global__ __launch_bounds__(NB) void k4_fill(const int32_t* __restrict__ ndup,
-                                              const int32_t* __restrict__ dup_anc,
-                                              const int32_t* __restrict__ free_slot,
-                                              int32_t* __restrict__ slot_anc) {
-    const int n = *ndup;
-    for (int k = blockIdx.x * NB + threadIdx.x; k < n; k += gridDim.x * NB)
-        slot_anc[free_slot[k]] = dup_anc[k];
-}
-
 // S3P:805-812 + the first stage of S3P:814-820. Sources are slots that keep themselves, so the
 // in-place parallel copy reads nothing that this launch writes. Per block: the first index of
 // the block's strict maximum of the NEW weights above 0.
-__global__ __launch_bounds__(NB) void k4_apply_w(const int32_t* __restrict__ slot_anc, int Pg,
-                                                 double* w, float* logw, double* bbest_v,
-                                                 int32_t* bbest_i) {
+// POSE: the handle holds all particles (one GPU), the pose rows move in the same launch.
+template <bool POSE>
+__global__ __launch_bounds__(NB) void k4_apply(int32_t* __restrict__ slot_anc,
+                                               const int32_t* __restrict__ dup_anc, int Pg,
+                                               double* w, float* logw, double* pose,
+                                               double* bbest_v, int32_t* bbest_i) {
     __shared__ double sv[NB / WAVE];
     __shared__ int si[NB / WAVE];
     const int g = blockIdx.x * NB + threadIdx.x;
@@ -412,9 +426,16 @@ __global__ __launch_bounds__(NB) void k4_apply_w(const int32_t* __restrict__ slo
     double v = 0.0;
     int idx = -1;
     if (g < Pg) {
-        const int a = slot_anc[g];
+        int a = slot_anc[g];
+        if (a < 0) { a = dup_anc[-1 - a]; slot_anc[g] = a; }   // k-th free slot <- k-th duplicate
         v = w[a];
-        if (a != g) { w[g] = v; logw[g] = logw[a]; }
+        if (a != g) {
+            w[g] = v; logw[g] = logw[a];
+            if (POSE) {
+#pragma unroll
+                for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * Pg + g] = pose[(size_t)k * Pg + a];
+            }
+        }
         if (v > 0.0) idx = g; else v = 0.0;                 // NaN and <= 0 never win (S3P:816)
     }
     // wave arg-max: larger value wins, ties go to the lower index
@@ -499,9 +520,11 @@ __global__ __launch_bounds__(NB) void k_apply_maps(const int32_t* __restrict__ s
 static inline int nblocks(int n) { return (n + NB - 1) / NB; }
 
 hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
-                       double* cdf, double* scratch, bool exact, PfResampleScratch sc) {
+                       double* cdf, double* scratch, bool exact, int32_t* first,
+                       unsigned long long* counters, PfResampleScratch sc) {
     if (exact) {
-        hipLaunchKernelGGL(k_weights_exact, dim3(1), dim3(WG), 0, st, scores, Pg, w, logw, cdf, scratch);
+        hipLaunchKernelGGL(k_weights_exact, dim3(1), dim3(WG), 0, st, scores, Pg, w, logw, cdf, scratch,
+                           first, counters);
         return hipGetLastError();
     }
     const int nb = nblocks(Pg);
@@ -509,7 +532,8 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
     hipLaunchKernelGGL(k3_raw, dim3(nb), dim3(NB), 0, st, scores, Pg, w, scratch, sc.prm, sc.bsum,
                        sc.bmax, sc.bse);
     hipLaunchKernelGGL(k3_combine, dim3(1), dim3(WG), 0, st, nb, sc.bsum, sc.bmax, sc.bse, sc.boff, sc.prm);
-    hipLaunchKernelGGL(k3_norm, dim3(nb), dim3(NB), 0, st, Pg, w, scratch, logw, sc.prm, sc.boff, cdf);
+    hipLaunchKernelGGL(k3_norm, dim3(nb), dim3(NB), 0, st, Pg, w, scratch, logw, sc.prm, sc.boff, cdf,
+                       first, counters);
     return hipGetLastError();
 }
 
@@ -521,27 +545,26 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
                         int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
                         unsigned long long* counters, PfResampleScratch sc) {
     const int nb = nblocks(Pg);
-    hipError_t e = hipMemsetAsync(counters, 0, 3 * sizeof(unsigned long long), st);   // [3] holds best
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(first, 0x7f, sizeof(int32_t) * (size_t)Pg, st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, bound, draw, counters, 0);
-    if (bound > 0.0) {
+    // counters[0..2] and first[] were initialised by the weight kernels of this step
+    hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, bound, draw, counters);
+    if (bound > 0.0)
         // settle draws that sit within the parallel CDF's rounding error of a boundary on the
-        // sequential-order CDF of the same weights (both kernels return at once when there are none)
+        // sequential-order CDF of the same weights (returns at once when there are none)
         hipLaunchKernelGGL(k_cdf_exact_if, dim3(1), dim3(WG), 0, st, w, Pg, (double*)cdf, counters);
-        hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, 0.0, draw, counters, 1);
-    }
-    hipLaunchKernelGGL(k_first, dim3(nb), dim3(NB), 0, st, draw, Pg, first);
+    hipLaunchKernelGGL(k_first, dim3(nb), dim3(NB), 0, st, cdf, u, draw, Pg, first, counters);
     hipLaunchKernelGGL(k4_count, dim3(nb), dim3(NB), 0, st, draw, Pg, first, sc.bcnt);
     hipLaunchKernelGGL(k4_scan, dim3(1), dim3(WG), 0, st, nb, sc.bcnt, sc.boff2, sc.ndup);
     hipLaunchKernelGGL(k4_scatter, dim3(nb), dim3(NB), 0, st, draw, Pg, first, sc.boff2, dup_anc,
                        free_slot, slot_anc);
-    hipLaunchKernelGGL(k4_fill, dim3(nb < 64 ? nb : 64), dim3(NB), 0, st, sc.ndup, dup_anc, free_slot,
-                       slot_anc);
-    hipLaunchKernelGGL(k4_apply_w, dim3(nb), dim3(NB), 0, st, slot_anc, Pg, w, logw, sc.bbest_v, sc.bbest_i);
-    hipLaunchKernelGGL(k_apply_pose, dim3(nblocks(P)), dim3(NB), 0, st, slot_anc, P, offset, pose,
-                       pose_gathered);
+    if (P == Pg && !pose_gathered) {
+        hipLaunchKernelGGL(k4_apply<true>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
+                           pose, sc.bbest_v, sc.bbest_i);
+    } else {
+        hipLaunchKernelGGL(k4_apply<false>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
+                           pose, sc.bbest_v, sc.bbest_i);
+        hipLaunchKernelGGL(k_apply_pose, dim3(nblocks(P)), dim3(NB), 0, st, slot_anc, P, offset, pose,
+                           pose_gathered);
+    }
     if (maps && map_stride) {
         unsigned long long n16 = (map_bytes + 15) / 16;
         int gy = (int)((n16 + 256ull * 8 - 1) / (256ull * 8));

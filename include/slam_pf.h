@@ -167,7 +167,11 @@ int pf_read_local_map(pf_handle* h, int8_t* dst);
 int pf_reset_local_map(pf_handle* h);                    /* S3P:750-754 */
 
 /* ---- plumbing ------------------------------------------------------------------------------ */
-void* pf_stream(pf_handle* h);                           /* the handle's hipStream_t */
+void* pf_stream(pf_handle* h);                           /* the hipStream_t the handle works on */
+/* Make the handle enqueue on the CALLER's hipStream_t (e.g. the stream its RCCL collectives
+ * are ordered against), so that hand-offs need no host synchronisation; NULL returns to the
+ * handle's own stream. The caller keeps ownership of its stream. */
+int pf_set_stream(pf_handle* h, void* hip_stream);
 int pf_synchronize(pf_handle* h);
 /* HIP-event timing of the kernels, per class; off by default. */
 int pf_profile(pf_handle* h, int enable);

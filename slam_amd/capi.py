@@ -23,7 +23,7 @@ SYMBOLS = (
     "pf_get_weights pf_fill_maps pf_write_map pf_broadcast_map pf_read_map pf_set_beams "
     "pf_measure pf_get_scores pf_scores_device pf_voxel_indices pf_weights pf_resample "
     "pf_poses_device pf_set_scan pf_update_map pf_write_local_map pf_read_local_map "
-    "pf_reset_local_map pf_stream pf_synchronize pf_profile pf_kernel_time "
+    "pf_reset_local_map pf_stream pf_set_stream pf_synchronize pf_profile pf_kernel_time "
     "pfh_snapshot_beams pfh_predict pfh_draw_noise pfh_draw_uniform pfh_add_points_policy "
     "pfh_permute").split()
 
@@ -106,6 +106,7 @@ class Handle:
         self.Pg = cfg.n_particles_global
         self.elements = cfg.grid_x * cfg.grid_y * cfg.grid_z
         self.local_elements = cfg.local_x * cfg.local_y * cfg.local_z
+        self.external_stream = False
 
     def close(self):
         if self._h:
@@ -253,6 +254,11 @@ class Handle:
     # --- plumbing ---
     def stream(self):
         return lib().pf_stream(self._h)
+
+    def set_stream(self, hip_stream):
+        """Work on the caller's stream (an int/pointer, e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._ck(lib().pf_set_stream(self._h, C.c_void_p(hip_stream)), "pf_set_stream")
+        self.external_stream = bool(hip_stream)
 
     def synchronize(self):
         self._ck(lib().pf_synchronize(self._h), "pf_synchronize")

@@ -22,7 +22,8 @@ struct EventPair { hipEvent_t a, b; };
 
 struct pf_handle {
     pf_config cfg;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream in use (own_stream or the caller's)
+    hipStream_t own_stream = nullptr;
     std::string err;
     // sizes
     int P = 0, Pg = 0, offset = 0;
@@ -189,7 +190,7 @@ void pf_destroy(pf_handle* h) {
     for (auto& v : h->ev) for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->h_result) (void)hipHostFree(h->h_result);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
 
@@ -265,7 +266,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
         }                                                                                    \
     } while (0)
     CREATE_TRY(hipSetDevice(c.device));
-    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
     const size_t P = h->P, Pg = h->Pg;
     CREATE_TRY(dalloc(&h->pose, PF_POSE_ROWS * P));
     CREATE_TRY(dalloc(&h->w, Pg));
@@ -459,7 +461,10 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         b.v = bv[j]; b.pad = 0;
         if (b.v > h->cfg.occ_threshold) {                                   // S3P:886
             h->h_beams_occ.push_back(b);
-            h->h_beams_occ_f.push_back(PfBeamF{(float)bx[j], (float)by[j], (float)bz[j], b.v});
+            // v of the fp32 list = flags: bit 0 = first beam of a vertical column (S3P:868 order)
+            const bool newcol = h->h_beams_occ_f.empty() || h->h_beams_occ_f.back().lx != (float)bx[j] ||
+                                h->h_beams_occ_f.back().ly != (float)by[j];
+            h->h_beams_occ_f.push_back(PfBeamF{(float)bx[j], (float)by[j], (float)bz[j], newcol ? 1 : 0});
             lmax = fmax(lmax, fmax(fabs(b.lx) + fabs(b.ly), fabs(b.lz)));
         }
     }
@@ -474,7 +479,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     while (h->h_beams_occ.size() % PF_BEAM_GROUP) {
         PfBeam d{}; d.lx = -3.0e7; d.ly = 0; d.lz = 0; d.v = 127;
         h->h_beams_occ.push_back(d);
-        h->h_beams_occ_f.push_back(PfBeamF{-3.0e7f, 0.f, 0.f, 127});
+        h->h_beams_occ_f.push_back(PfBeamF{-3.0e7f, 0.f, 0.f, 1});
     }
     const size_t no = h->h_beams_occ.size();
     if (no) {
@@ -705,6 +710,14 @@ int pf_reset_local_map(pf_handle* h) {
     NEED(h, h->local, "no local map");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemsetAsync(h->local, 0, (size_t)h->local_elements, h->stream));
+    return PF_OK;
+}
+
+int pf_set_stream(pf_handle* h, void* hip_stream) {
+    if (!h) return PF_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));            // nothing of ours left on the old one
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return PF_OK;
 }
 

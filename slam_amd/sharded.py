@@ -52,18 +52,28 @@ class ShardedBackend:
         if t.is_cuda:
             self.torch.cuda.current_stream(t.device).synchronize()
 
+    def _before_collective(self):
+        # handle on its own stream: its work must be complete before the collective reads it;
+        # handle on torch's current stream (pf_set_stream): stream order already says so
+        if not getattr(self.h, "external_stream", False):
+            self.h.synchronize()
+
+    def _after_collective(self, t):
+        if not getattr(self.h, "external_stream", False):
+            self._sync_device(t)
+
     def weights(self):
-        self.h.synchronize()                       # local scores complete on the handle's stream
+        self._before_collective()
         s = self.h.scores_tensor()
         self.dist.all_gather_into_tensor(self._scores_all, s, group=self.group)     # C1
-        self._sync_device(self._scores_all)
+        self._after_collective(self._scores_all)
         self.h.weights(self._scores_all.data_ptr())
 
     def resample(self, u=None, want_slots=True):
-        self.h.synchronize()                       # uploaded poses complete
+        self._before_collective()
         p = self.h.poses_tensor()
         self.dist.all_gather_into_tensor(self._poses_all, p, group=self.group)      # C2
-        self._sync_device(self._poses_all)
+        self._after_collective(self._poses_all)
         return self.h.resample(u, self._poses_all.data_ptr(), want_slots)
 
     def best_pose(self, best):

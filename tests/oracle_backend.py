@@ -30,6 +30,7 @@ class OracleHandle:
         self.logw = np.zeros(self.Pg, np.float32)
         self.best = 0
         self.scores = np.zeros((P, 2), np.int32)
+        self.external_stream = False
 
     # state
     def predict(self, x, y, z, yaw):

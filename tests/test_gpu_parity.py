@@ -396,3 +396,88 @@ def test_predict_device_equals_predict():
             h.close()
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)
+
+
+def test_per_particle_fuse_with_collisions_matches_oracle():
+    """K1+K2 on per-particle maps at a size between the reference's and configs[3]: random
+    beams (many collide after rotation + rounding), mixed signs, several steps; every map
+    byte, score and slot against the oracle. The order-dependent clamp-add of S3P:892-904 is
+    what this pins."""
+    P, dims, M = 300, (64, 64, 32), 5000
+    rng = np.random.default_rng(17)
+    grid0 = rng.integers(0, 101, dims).astype(np.uint8)
+    x = rng.uniform(1.2, 2.0, P); y = rng.uniform(1.2, 2.0, P); z = rng.uniform(0.6, 1.0, P)
+    yaw = rng.uniform(-3.2, 3.2, P)
+    lin = np.sort(rng.choice(41 * 41 * 21, M, replace=False))       # ascending flat order, distinct
+    bx = (lin // (41 * 21) - 20).astype(np.int32); by = ((lin // 21) % 41 - 20).astype(np.int32)
+    bz = (lin % 21 - 10).astype(np.int32)
+    bv = rng.choice(np.array([-50, -9, -3, 3, 10, 21, 30, 50], np.int8), M)
+    og = O.ref_grid(*dims)
+    maps = np.tile(grid0.reshape(1, -1), (P, 1))
+    w = np.full(P, 1.0 / P)
+    cfg = capi.default_config(n_particles=P, grid_x=dims[0], grid_y=dims[1], grid_z=dims[2],
+                              local_x=0, local_y=0, local_z=0)
+    h = capi.Handle(cfg)
+    try:
+        h.broadcast_map(grid0); h.predict(x, y, z, yaw); h.set_weights(w)
+        h.set_beams(bx, by, bz, bv)
+        for step in range(3):
+            add = 1 if step != 1 else 0
+            s, c = O.measure(og, x, y, z, yaw, maps.reshape(-1), maps.shape[1], bx, by, bz, bv, add)
+            h.measure(add)
+            gs, gc = h.get_scores()
+            assert np.array_equal(gs, s) and np.array_equal(gc, c), step
+            O.weights(w, s, int(c[-1])); h.weights()
+            gw, _ = h.get_weights()
+            assert np.array_equal(gw, w), step
+            u = capi.draw_uniform(500 + step, P)
+            d, sa, best, nohit = O.resample(w, u, 0)
+            slots, gbest, gnohit, amb = h.resample(u)
+            assert np.array_equal(slots, sa) and gnohit == nohit, step
+            O.permute(sa, maps)
+            for arr in (x, y, z, yaw):
+                O.permute(sa, arr)
+            for i in range(0, P, 7):
+                assert np.array_equal(h.read_map(i), maps[i]), (step, i)
+        assert len(np.unique([zlib.crc32(maps[i].tobytes()) for i in range(P)])) > 1
+    finally:
+        h.close()
+
+
+def test_sharded_backend_on_rccl_single_rank():
+    """The multi-GPU code path (slam_amd/sharded.py: zero-copy torch views of the library's
+    device buffers, all_gather_into_tensor on the nccl = RCCL backend, gathered pointers into
+    pf_weights / pf_resample) with the one rank this box has: must equal the plain handle."""
+    import torch
+    import torch.distributed as dist
+    from slam_amd.sharded import ShardedBackend
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29655")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        P, M, dims = 4000, 700, (96, 96, 64)
+        sc = synth.scene(dims, P, M, seed=31)
+        u = capi.draw_uniform(8, P)
+        out = []
+        for sharded in (False, True):
+            h = capi.Handle(_shared_cfg(P, dims))
+            be = ShardedBackend(h, dist) if sharded else h
+            try:
+                h.write_map(0, sc["grid"]); be.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+                be.set_beams(*sc["beams"]); be.measure(0); be.weights()
+                w, lw = h.get_weights()
+                r = be.resample(u)
+                out.append((w, lw, r[0], r[1], np.stack(h.get_poses())))
+                if sharded:
+                    bp = be.best_pose(r[1])
+                    assert bp == tuple(np.stack(h.get_poses())[:, r[1]])
+            finally:
+                h.close()
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b)
+    finally:
+        if created:
+            dist.destroy_process_group()

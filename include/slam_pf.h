@@ -166,6 +166,20 @@ int pf_write_local_map(pf_handle* h, const int8_t* src);
 int pf_read_local_map(pf_handle* h, int8_t* dst);
 int pf_reset_local_map(pf_handle* h);                    /* S3P:750-754 */
 
+/* ---- scan-to-map vote: S3P:328-376 (the per-frame localiser) ------------ */
+
+/* Counts, for every pose hypothesis, the scan points that land on set cells of the handle's
+ * SHARED uint8 grid (the reference's map_localization, S3P:64: create the handle with
+ * PF_MAP_SHARED and that grid's dims). points: n_points rows of sensor-frame xyz (the 500
+ * sampled points of S3P:318-323, drawn by the caller). Yaw hypothesis r = zyx[0] +
+ * (yaw_k0 + yaw_kstep*r)*pi/180 (S3P:329: -6, 3, n_yaw 5); translations pos + a*resolution -
+ * (length - resolution)/2 per axis, a < n_t (S3P:335: length 0.25, n_t 5). sums_out (may be
+ * NULL): int32 [n_yaw*n_t^3] in the reference's loop order r, x, y, z; *best_out = index of the
+ * first strict maximum above 0 (S3P:365) or -1. The epilogue S3P:379-404 stays with the caller. */
+int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const double pos[3],
+                 const double zyx[3], int32_t n_yaw, int32_t yaw_k0, int32_t yaw_kstep,
+                 int32_t n_t, double length, int32_t* sums_out, int64_t* best_out);
+
 /* ---- plumbing ------------------------------------------------------------------------------ */
 void* pf_stream(pf_handle* h);                           /* the hipStream_t the handle works on */
 /* Make the handle enqueue on the CALLER's hipStream_t (e.g. the stream its RCCL collectives

@@ -22,7 +22,7 @@ SYMBOLS = (
     "pf_default_config pf_create pf_destroy pf_last_error pf_predict pf_predict_device pf_get_poses pf_set_weights "
     "pf_get_weights pf_fill_maps pf_write_map pf_broadcast_map pf_read_map pf_set_beams "
     "pf_measure pf_get_scores pf_scores_device pf_voxel_indices pf_weights pf_resample "
-    "pf_poses_device pf_set_scan pf_update_map pf_write_local_map pf_read_local_map "
+    "pf_poses_device pf_set_scan pf_update_map pf_scan_vote pf_write_local_map pf_read_local_map "
     "pf_reset_local_map pf_stream pf_set_stream pf_synchronize pf_profile pf_kernel_time "
     "pfh_snapshot_beams pfh_predict pfh_draw_noise pfh_draw_uniform pfh_add_points_policy "
     "pfh_permute").split()
@@ -237,6 +237,16 @@ class Handle:
         pos = _c(pos, np.float64); zyx = _c(zyx, np.float64)
         self._ck(lib().pf_update_map(self._h, int(target), C.byref(params), _p(pos), _p(zyx)),
                  "pf_update_map")
+
+    def scan_vote(self, points, pos, zyx, n_yaw=5, yaw_k0=-6, yaw_kstep=3, n_t=5, length=0.25):
+        points = _c(points, np.float64).reshape(-1, 3)
+        pos = _c(pos, np.float64); zyx = _c(zyx, np.float64)
+        sums = np.empty(n_yaw * n_t ** 3, np.int32)
+        best = C.c_int64(-1)
+        self._ck(lib().pf_scan_vote(self._h, _p(points), C.c_int64(len(points)), _p(pos), _p(zyx),
+                                    n_yaw, yaw_k0, yaw_kstep, n_t, C.c_double(length), _p(sums),
+                                    C.byref(best)), "pf_scan_vote")
+        return sums, best.value
 
     def write_local_map(self, src):
         src = _c(src, np.int8).reshape(-1)

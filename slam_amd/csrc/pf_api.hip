@@ -689,6 +689,71 @@ int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const dou
     return PF_OK;
 }
 
+int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const double pos[3],
+                 const double zyx[3], int32_t n_yaw, int32_t yaw_k0, int32_t yaw_kstep,
+                 int32_t n_t, double length, int32_t* sums_out, int64_t* best_out) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, h->cfg.map_mode == PF_MAP_SHARED, "needs a PF_MAP_SHARED handle (the grid voted on)");
+    NEED(h, pos && zyx && best_out, "null argument");
+    NEED(h, n_points >= 0 && n_points <= h->cfg.max_points && (n_points == 0 || points), "n_points beyond max_points");
+    NEED(h, n_yaw >= 1 && n_yaw <= 64 && n_t >= 1 && n_t <= 16, "lattice size");
+    for (int64_t i = 0; i < 3 * n_points; ++i)
+        if (!(fabs(points[i]) < 1.0e6)) return fail(h, PF_ERR_ARG, "pf_scan_vote: point %lld not finite/too far", (long long)(i / 3));
+    const double pi = 2 * acos(0.0);                              // S3P:24
+    const double res = h->cfg.resolution;
+    const int per = n_t * n_t * n_t, nh = n_yaw * per;
+    std::vector<double> mats(9 * (size_t)n_yaw), trans(3 * (size_t)nh);
+    for (int r = 0; r < n_yaw; ++r) {
+        const double z = zyx[0] + (yaw_k0 + yaw_kstep * r) * pi / 180, y = zyx[1], x = zyx[2];   // S3P:329
+        double* m = &mats[9 * (size_t)r];
+        m[0] = cos(y) * cos(z);                                   // S3P:536-544
+        m[1] = cos(z) * sin(x) * sin(y) - cos(x) * sin(z);
+        m[2] = sin(x) * sin(z) + cos(x) * cos(z) * sin(y);
+        m[3] = cos(y) * sin(z);
+        m[4] = cos(x) * cos(z) + sin(x) * sin(y) * sin(z);
+        m[5] = cos(x) * sin(y) * sin(z) - cos(z) * sin(x);
+        m[6] = -sin(y);
+        m[7] = cos(y) * sin(x);
+        m[8] = cos(x) * cos(y);
+        int k = r * per;
+        for (int a = 0; a < n_t; ++a)
+            for (int b = 0; b < n_t; ++b)
+                for (int d = 0; d < n_t; ++d, ++k) {              // S3P:335, 341, 348
+                    trans[3 * (size_t)k + 0] = pos[0] + a * res - (length - res) / 2;
+                    trans[3 * (size_t)k + 1] = pos[1] + b * res - (length - res) / 2;
+                    trans[3 * (size_t)k + 2] = pos[2] + d * res - (length - res) / 2;
+                }
+    }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    // scratch for this call: matrices, translations, rotated points, sums (not a per-frame hot
+    // allocation problem at 625 hypotheses x 500 points; kept simple)
+    const size_t nb_m = sizeof(double) * mats.size(), nb_t = sizeof(double) * trans.size();
+    const size_t nb_r = sizeof(double) * 3 * (size_t)n_yaw * (size_t)(n_points ? n_points : 1);
+    const size_t nb_s = sizeof(int32_t) * (size_t)nh;
+    char* dev = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&dev, nb_m + nb_t + nb_r + nb_s + 64));
+    double* d_m = (double*)dev; double* d_t = (double*)(dev + nb_m);
+    double* d_r = (double*)(dev + nb_m + nb_t); int32_t* d_s = (int32_t*)(dev + nb_m + nb_t + nb_r);
+    std::vector<int32_t> sums((size_t)nh);
+    hipError_t e = hipMemcpyAsync(d_m, mats.data(), nb_m, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_t, trans.data(), nb_t, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && n_points)
+        e = hipMemcpyAsync(h->points, points, sizeof(double) * 3 * (size_t)n_points, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess)
+        e = pfk_scan_vote(h->stream, h->maps, h->points, (int)n_points, d_m, n_yaw, d_t, per, 1 / res,
+                          h->cfg.grid_y, h->cfg.grid_z, h->elements, d_r, d_s);
+    if (e == hipSuccess) e = hipMemcpyAsync(sums.data(), d_s, nb_s, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(h, PF_ERR_HIP, "pf_scan_vote: %s", hipGetErrorString(e));
+    int64_t best = -1; int32_t best_sum = 0;                      // S3P:326, 365
+    for (int k = 0; k < nh; ++k)
+        if (sums[(size_t)k] > best_sum) { best_sum = sums[(size_t)k]; best = k; }
+    *best_out = best;
+    if (sums_out) memcpy(sums_out, sums.data(), nb_s);
+    return PF_OK;
+}
+
 int pf_write_local_map(pf_handle* h, const int8_t* src) {
     if (!h) return PF_ERR_ARG;
     NEED(h, src && h->local, "no local map / null src");

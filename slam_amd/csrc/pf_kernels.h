@@ -100,3 +100,10 @@ hipError_t pfk_update_hits(hipStream_t st, void* grid, const double* points, int
 hipError_t pfk_update_rays(hipStream_t st, void* grid, const double* wpts, const int32_t* ray_idx,
                            int R, PfUpdateParams up);
 hipError_t pfk_fill_u8(hipStream_t st, uint8_t* dst, unsigned long long n, int value);
+
+// K6: S3P:328-376. mats: double [n_yaw][9]; trans: double [n_yaw*n_per_yaw][3]; rot: scratch
+// double [n_yaw][N][3]; sums: int32 [n_yaw*n_per_yaw].
+hipError_t pfk_scan_vote(hipStream_t st, const uint8_t* grid, const double* points, int N,
+                         const double* mats, int n_yaw, const double* trans, int n_per_yaw,
+                         double conv, int gy, int gz, long long elements, double* rot,
+                         int32_t* sums);

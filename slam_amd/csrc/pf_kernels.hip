@@ -433,3 +433,59 @@ hipError_t pfk_fill_u8(hipStream_t st, uint8_t* dst, unsigned long long n, int v
                        make_uint4(w, w, w, w));
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------
+// K6 scan vote: S3P:328-376 (scan-to-map localisation). n_yaw x n_t^3 pose hypotheses, each
+// counts the points that land on set cells of a uint8 grid. Rotation per yaw hypothesis first
+// (S3P:332, matrices from the host libm), then one workgroup per hypothesis, lanes over points,
+// integer block reduction. Same flat-only bounds rule (S3P:358: >=).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vote_rotate(const double* __restrict__ points, int N,
+                                                     const double* __restrict__ mats,
+                                                     double* __restrict__ rot) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (i >= N) return;
+    const double* m = mats + 9 * r;
+    const double px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
+    double* o = rot + 3 * ((size_t)r * N + i);
+    o[0] = m[0] * px + m[1] * py + m[2] * pz;             // S3P:547-549
+    o[1] = m[3] * px + m[4] * py + m[5] * pz;
+    o[2] = m[6] * px + m[7] * py + m[8] * pz;
+}
+__global__ __launch_bounds__(256) void k_vote(const uint8_t* __restrict__ grid,
+                                              const double* __restrict__ rot, int N,
+                                              const double* __restrict__ trans, int n_per_yaw,
+                                              double conv, int gy, int gz, long long elements,
+                                              int32_t* __restrict__ sums) {
+    __shared__ int sh[4];
+    const int hyp = blockIdx.x;
+    const int r = hyp / n_per_yaw;
+    const double tx = trans[3 * (size_t)hyp], ty = trans[3 * (size_t)hyp + 1], tz = trans[3 * (size_t)hyp + 2];
+    int sum = 0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const double* q = rot + 3 * ((size_t)r * N + i);
+        // S3P:337-355: loc = rot + T per axis, idx = round(loc * map_conv)
+        const double X = round((q[0] + tx) * conv), Y = round((q[1] + ty) * conv), Z = round((q[2] + tz) * conv);
+        if (!(fabs(X) < 2147483648.0 && fabs(Y) < 2147483648.0 && fabs(Z) < 2147483648.0)) continue;
+        const long long f = (long long)X * gy * gz + (long long)Y * gz + (long long)Z;
+        if (f < 0 || f >= elements) continue;              // S3P:358
+        sum += grid[f];                                    // S3P:361
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[hyp] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+hipError_t pfk_scan_vote(hipStream_t st, const uint8_t* grid, const double* points, int N,
+                         const double* mats, int n_yaw, const double* trans, int n_per_yaw,
+                         double conv, int gy, int gz, long long elements, double* rot,
+                         int32_t* sums) {
+    if (N > 0)
+        hipLaunchKernelGGL(k_vote_rotate, dim3((N + 255) / 256, n_yaw), dim3(256), 0, st, points, N,
+                           mats, rot);
+    hipLaunchKernelGGL(k_vote, dim3(n_yaw * n_per_yaw), dim3(256), 0, st, grid, rot, N, trans,
+                       n_per_yaw, conv, gy, gz, elements, sums);
+    return hipGetLastError();
+}

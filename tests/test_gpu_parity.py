@@ -481,3 +481,43 @@ def test_sharded_backend_on_rccl_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed,n_points", [(21, 500), (22, 37), (23, 0)])
+def test_scan_vote_matches_oracle(seed, n_points):
+    """S3P:328-376 (625 pose hypotheses x 500 points on the binary localisation grid).
+    PARITY UNPINNED by the reference (scan_localization is a class member, not buildable
+    here; see oracle/pf_oracle.h): checked against the restatement, integer-exact."""
+    rng = np.random.default_rng(seed)
+    dims = (200, 200, 80)
+    world = synth.make_room(dims, seed=seed)
+    grid = (world > 50).astype(np.uint8)               # S3P:697-699: map_localization is 0/1
+    pos = np.array([5.0, 5.0, 1.5]) + rng.normal(0, 0.05, 3)
+    zyx = np.array([rng.uniform(-3, 3), rng.normal(0, 0.02), rng.normal(0, 0.02)])
+    # points near set cells, expressed in the sensor frame, plus far ones that fall outside
+    occ = np.argwhere(grid > 0)
+    pick = occ[rng.integers(0, len(occ), n_points)] if n_points else np.zeros((0, 3), np.int64)
+    wp = pick * 0.05 + rng.normal(0, 0.02, (n_points, 3))
+    R = np.array(O.rot_zyx(*zyx)).reshape(3, 3) if hasattr(O, "rot_zyx") else None
+    if R is None:
+        cz, sz = np.cos(zyx[0]), np.sin(zyx[0])
+        R = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    pts = (wp - pos) @ R                                # R^T (wp - pos) per row
+    if n_points > 8:
+        pts[:4] *= 40.0                                 # off the grid (flat-only bounds rule)
+        pts[4] = [1e5, -1e5, 3e5]                       # far outside the grid
+    want, want_best = O.scan_vote(grid, 0.05, pts, pos, zyx)
+    h = capi.Handle(capi.default_config(n_particles=1, map_mode=capi.PF_MAP_SHARED,
+                                        grid_x=dims[0], grid_y=dims[1], grid_z=dims[2],
+                                        max_points=1024))
+    try:
+        h.write_map(0, grid.reshape(-1))
+        got, got_best = h.scan_vote(pts, pos, zyx)
+    finally:
+        h.close()
+    assert np.array_equal(got, want)
+    assert got_best == want_best
+    if n_points >= 100:
+        assert want.max() > n_points // 4               # the case does vote
+    if n_points == 0:
+        assert got_best == -1

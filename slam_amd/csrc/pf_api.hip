@@ -38,10 +38,15 @@ struct pf_handle {
     double* scratch = nullptr;         // [Pg+1]
     double* u = nullptr;               // [Pg]
     uint8_t* maps = nullptr;           // shared grid or P slabs
+    uint8_t* shadow = nullptr;         // shared grid again, in K1's gather layout (PfSwz), or null
+    bool shadow_dirty = true;          // maps changed by something other than K5 since the last build
+    PfSwz swz{};
+    double* sorted = nullptr;          // [5][P] pose rows in lane order (written with order[])
     int8_t* local = nullptr;           // local int8 map
     PfBeam* beams = nullptr;           // [max_beams] every beam (fuse path, voxel indices)
     PfBeam* beams_occ = nullptr;       // [max_beams] occupied beams only (fast measure path)
     PfBeamF* beams_occ_f = nullptr;    // [max_beams] the same in fp32
+    PfBeamG* beams_occ_g = nullptr;    // [max_beams/4 + 1] the same in groups of four (k_measure_swz)
     int M_occ = 0;                     // padded to a multiple of PF_BEAM_GROUP
     int M_occ_real = 0;
     double lmax_occ = 0;               // max over occupied beams of max(|lx|+|ly|, |lz|)
@@ -70,6 +75,7 @@ struct pf_handle {
     std::vector<double> h_pose;
     std::vector<PfBeam> h_beams, h_beams_occ;
     std::vector<PfBeamF> h_beams_occ_f;
+    std::vector<PfBeamG> h_beams_occ_g;
     int tune_chunks = 0;               // SLAM_PF_CHUNKS (development knob)
     int force_exact_measure = 0;       // SLAM_PF_EXACT_MEASURE=1: fp64-only kernel
     int max_chunks = 1;
@@ -183,7 +189,7 @@ void pf_destroy(pf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f,
+    void* ptrs[] = {h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_occ_g,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
                     h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -278,11 +284,25 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     const unsigned long long map_bytes =
         c.map_mode == PF_MAP_PER_PARTICLE ? h->slab * P : round_up((unsigned long long)h->elements, 256);
     CREATE_TRY(dalloc(&h->maps, (size_t)map_bytes));
+    CREATE_TRY(dalloc(&h->sorted, 5 * P));
+    {
+        // gather-layout copy for K1 when the 24-bit multiplies and 32-bit byte offsets of
+        // swz_addr hold (any grid up to 1024^3 does); otherwise K1 reads the reference order
+        const unsigned long long gx = c.grid_x, gy = c.grid_y, gz = c.grid_z;
+        const unsigned long long sbytes = gx * gy * 8ull * ((gz + 7) / 8);
+        if (c.map_mode == PF_MAP_SHARED && gx * gy * 8ull <= (1ull << 24) && sbytes < (1ull << 32) &&
+            h->elements < (1ll << 31) && !getenv("SLAM_PF_NO_GATHER_LAYOUT")) {
+            CREATE_TRY(dalloc(&h->shadow, (size_t)round_up(sbytes, 256)));
+            h->swz = PfSwz{(uint32_t)gx, (uint32_t)gy, (uint32_t)gz, (uint32_t)(gy * 8),
+                           (uint32_t)(gx * gy * 8 - 8)};
+        }
+    }
     if (h->local_elements)
         CREATE_TRY(dalloc(&h->local, (size_t)round_up((unsigned long long)h->local_elements, 256)));
     CREATE_TRY(dalloc(&h->beams, (size_t)c.max_beams));
-    CREATE_TRY(dalloc(&h->beams_occ, (size_t)c.max_beams));
-    CREATE_TRY(dalloc(&h->beams_occ_f, (size_t)c.max_beams));
+    CREATE_TRY(dalloc(&h->beams_occ, (size_t)c.max_beams + PF_BEAM_GROUP));
+    CREATE_TRY(dalloc(&h->beams_occ_f, (size_t)c.max_beams + PF_BEAM_GROUP));
+    CREATE_TRY(dalloc(&h->beams_occ_g, (size_t)c.max_beams / PF_BEAM_GROUP + 1));
     if (const char* e = getenv("SLAM_PF_CHUNKS")) h->tune_chunks = atoi(e);
     if (const char* e = getenv("SLAM_PF_EXACT_MEASURE")) h->force_exact_measure = atoi(e);
     CREATE_TRY(dalloc(&h->partial, (size_t)h->max_chunks * P));
@@ -406,6 +426,7 @@ int pf_fill_maps(pf_handle* h, int value) {
     const unsigned long long bytes = h->slab ? h->slab * (unsigned long long)h->P
                                              : round_up((unsigned long long)h->elements, 256);
     HIP_TRY(h, pfk_fill_u8(h->stream, h->maps, bytes, value));
+    h->shadow_dirty = true;
     return PF_OK;
 }
 
@@ -417,6 +438,7 @@ int pf_write_map(pf_handle* h, int32_t i, const uint8_t* src) {
     HIP_TRY(h, hipMemcpyAsync(h->maps + h->slab * (unsigned long long)i, src, (size_t)h->elements,
                               hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->shadow_dirty = true;
     return PF_OK;
 }
 
@@ -425,6 +447,7 @@ int pf_broadcast_map(pf_handle* h, const uint8_t* src) {
     NEED(h, src, "null src");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemcpyAsync(h->maps, src, (size_t)h->elements, hipMemcpyHostToDevice, h->stream));
+    h->shadow_dirty = true;
     if (h->slab)
         for (int i = 1; i < h->P; ++i)
             HIP_TRY(h, hipMemcpyAsync(h->maps + h->slab * (unsigned long long)i, h->maps,
@@ -461,10 +484,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         b.v = bv[j]; b.pad = 0;
         if (b.v > h->cfg.occ_threshold) {                                   // S3P:886
             h->h_beams_occ.push_back(b);
-            // v of the fp32 list = flags: bit 0 = first beam of a vertical column (S3P:868 order)
-            const bool newcol = h->h_beams_occ_f.empty() || h->h_beams_occ_f.back().lx != (float)bx[j] ||
-                                h->h_beams_occ_f.back().ly != (float)by[j];
-            h->h_beams_occ_f.push_back(PfBeamF{(float)bx[j], (float)by[j], (float)bz[j], newcol ? 1 : 0});
+            h->h_beams_occ_f.push_back(PfBeamF{(float)bx[j], (float)by[j], (float)bz[j], 0});
             lmax = fmax(lmax, fmax(fabs(b.lx) + fabs(b.ly), fabs(b.lz)));
         }
     }
@@ -479,10 +499,19 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     while (h->h_beams_occ.size() % PF_BEAM_GROUP) {
         PfBeam d{}; d.lx = -3.0e7; d.ly = 0; d.lz = 0; d.v = 127;
         h->h_beams_occ.push_back(d);
-        h->h_beams_occ_f.push_back(PfBeamF{-3.0e7f, 0.f, 0.f, 1});
+        h->h_beams_occ_f.push_back(PfBeamF{-3.0e7f, 0.f, 0.f, 0});
     }
     const size_t no = h->h_beams_occ.size();
+    h->h_beams_occ_g.assign(no / PF_BEAM_GROUP, PfBeamG{});
+    for (size_t j = 0; j < no; ++j) {
+        PfBeamG& g = h->h_beams_occ_g[j / PF_BEAM_GROUP];
+        const PfBeam& b = h->h_beams_occ[j];
+        g.lx[j % PF_BEAM_GROUP] = (float)b.lx; g.ly[j % PF_BEAM_GROUP] = (float)b.ly;
+        g.lz[j % PF_BEAM_GROUP] = (int32_t)b.lz;
+    }
     if (no) {
+        HIP_TRY(h, hipMemcpyAsync(h->beams_occ_g, h->h_beams_occ_g.data(), sizeof(PfBeamG) * (no / PF_BEAM_GROUP),
+                                  hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->beams_occ, h->h_beams_occ.data(), sizeof(PfBeam) * no,
                                   hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->beams_occ_f, h->h_beams_occ_f.data(), sizeof(PfBeamF) * no,
@@ -494,6 +523,15 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     h->M_occ_real = n_real_occ;
     h->lmax_occ = lmax;
     return PF_OK;
+}
+
+static PfOrderParams order_params(const pf_handle* h) {
+    PfOrderParams op{500.0, 2.0, 4.0, 0};
+    if (const char* e = getenv("SLAM_PF_ORDER")) {
+        double a, x, y; int m;
+        if (sscanf(e, "%lf,%lf,%lf,%d", &a, &x, &y, &m) == 4) op = PfOrderParams{a, x, y, m};
+    }
+    return op;
 }
 
 int pf_measure(pf_handle* h, int add_points) {
@@ -516,13 +554,22 @@ int pf_measure(pf_handle* h, int add_points) {
     }
     if (!fuse && !h->force_exact_measure && h->order_dirty) {
         HIP_TRY(h, pfk_order(h->stream, h->pose, h->P, h->order_keys, h->order_hist[h->order_flip],
-                             h->order_hist[h->order_flip ^ 1], h->order));
+                             h->order_hist[h->order_flip ^ 1], h->order, h->sorted, order_params(h)));
         h->order_flip ^= 1;
         h->order_dirty = false;
     }
+    const bool swz = h->shadow && !fuse && !h->force_exact_measure;
+    if (swz && h->shadow_dirty) {
+        HIP_TRY(h, pfk_swz_build(h->stream, h->maps, h->shadow, h->swz));
+        h->shadow_dirty = false;
+    }
     {
         Timed t(h, PF_K_MEASURE);
-        if (fuse)
+        if (swz)
+            HIP_TRY(h, pfk_measure_swz(h->stream, h->sorted, h->P, h->shadow, h->swz, h->beams_occ_g,
+                                       h->beams_occ, Mk, chunks, bpc, grid_params(h), h->lmax_occ,
+                                       h->order, h->partial));
+        else if (fuse)
             HIP_TRY(h, pfk_measure(h->stream, h->pose, h->P, h->maps, h->slab, h->beams, h->M, 1, bpc,
                                    grid_params(h), true, h->partial));
         else if (h->force_exact_measure)
@@ -648,12 +695,15 @@ int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const dou
                   const double zyx[3]) {
     if (!h) return PF_ERR_ARG;
     NEED(h, p && pos && zyx, "null argument");
-    PfUpdateParams up;
+    PfUpdateParams up{};
     void* grid = nullptr;
     if (target == PF_GRID_SHARED) {
         NEED(h, h->cfg.map_mode == PF_MAP_SHARED, "PF_GRID_SHARED needs map_mode PF_MAP_SHARED");
         grid = h->maps; up.elements = h->elements; up.gy = h->cfg.grid_y; up.gz = h->cfg.grid_z;
         up.is_signed = 0;
+        if (h->shadow && !h->shadow_dirty) {        // keep K1's gather-layout copy in step
+            up.shadow = h->shadow; up.swz_gy8 = h->swz.gy8; up.swz_kz = h->swz.kz;
+        }
         NEED(h, p->hit_clamp >= 0 && p->hit_clamp <= 255 && p->miss_clamp >= 0 && p->miss_clamp <= 255, "clamps outside uint8");
     } else if (target == PF_GRID_LOCAL) {
         NEED(h, h->local != nullptr, "no local map configured");

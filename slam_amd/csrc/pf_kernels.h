@@ -13,10 +13,22 @@ struct PfBeam {
     int32_t pad;
 };
 
-// The same beam for the fp32 filter of the fast measure kernel (16 B, one s_load_dwordx4).
+// The same beam for the fp32 filter of the fast measure kernels (16 B, one s_load_dwordx4).
 struct PfBeamF {
     float lx, ly, lz;
     int32_t v;
+};
+// A group of PF_BEAM_GROUP occupied beams for k_measure_swz (64 B, scalar loads): lz as integers.
+struct __attribute__((aligned(64))) PfBeamG {
+    float lx[4], ly[4];
+    int32_t lz[4];
+    int32_t pad[4];
+};
+
+// Gather layout of the shared grid: byte address of cell (X, Y, Z) =
+// ((Z/8 * gx + X) * gy + Y) * 8 + Z%8; bytes = gx*gy*8*ceil(gz/8). gy8 = gy*8, kz = gx*gy*8 - 8.
+struct PfSwz {
+    uint32_t gx, gy, gz, gy8, kz;
 };
 
 // Pose block: double [PF_POSE_ROWS][n] = x, y, z, yaw, cos, sin, x/res, y/res, z/res.
@@ -47,8 +59,18 @@ hipError_t pfk_measure_fast(hipStream_t st, const double* pose, int P, const uin
 // int32 [PF_ORDER_BUCKETS] buffers used alternately (hist must be zero on entry; the call
 // leaves next_hist zeroed). keys: int32 [P] scratch.
 #define PF_ORDER_BUCKETS 32768
+struct PfOrderParams {
+    double qa, qx, qy;   // cells per radian of yaw / per voxel of x / per voxel of y
+    int32_t mode;        // 0: lexicographic yaw,x,y (6/4/5 bits)  1: Morton (5 bits each)
+};
+// sorted: double [5][P] = cos, sin, x/res, y/res, z/res in lane order (K1's prologue).
 hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, int32_t* hist,
-                     int32_t* next_hist, int32_t* order);
+                     int32_t* next_hist, int32_t* order, double* sorted, PfOrderParams op);
+// K1 on the gather layout (shared grid only). Same beam lists and chunking as pfk_measure_fast.
+hipError_t pfk_measure_swz(hipStream_t st, const double* sorted, int P, const uint8_t* shadow,
+                           PfSwz sw, const PfBeamG* bg, const PfBeam* bd, int M, int n_chunks, int bpc,
+                           PfGridParams gp, double lmax, const int32_t* order, int2* partial);
+hipError_t pfk_swz_build(hipStream_t st, const uint8_t* lin, uint8_t* shadow, PfSwz sw);
 hipError_t pfk_reduce_scores(hipStream_t st, const int2* partial, int n_chunks, int P, int2* scores);
 hipError_t pfk_voxel_indices(hipStream_t st, const double* pose, int P, int i, const PfBeam* beams,
                              int M, PfGridParams gp, int32_t* flat_out);
@@ -94,6 +116,8 @@ struct PfUpdateParams {
     int32_t gy, gz;
     int32_t hit_inc, hit_clamp, miss_inc, miss_clamp;
     int32_t is_signed;
+    void* shadow;         // gather-layout copy of the shared grid to keep in step, or null
+    uint32_t swz_gy8, swz_kz;
 };
 hipError_t pfk_update_hits(hipStream_t st, void* grid, const double* points, int M, double* wpts,
                            PfUpdateParams up);

@@ -84,10 +84,16 @@ struct FastLane {
     float cf, sf, msf, txf, tyf, zpf, thr;
 };
 
-// z needs no per-beam rounding: lz is an integer, so round(fl64(lz + tz)) = lz + rint(tz)
-// unless tz lies within the filter's error of a half-integer. That is a property of the LANE,
-// decided once: such a lane gets thr = -1, which sends every beam of its wave down the
-// reference fp64 sequence.
+// z needs no per-beam rounding: lz is an integer, so the reference's round(fl64(lz + tz)) equals
+// lz + round(tz) whenever tz is not within the fp64 rounding error of lz + tz of a half-integer
+// (a tie included). |lz + tz| < 2^25 (validated by the host), so that error is at most 2^-28;
+// the window used is 2^-20. That is a property of the LANE, decided once in fp64: such a lane
+// (about 2 in a million) gets thr = -1, which sends every beam of its wave down the reference
+// fp64 sequence.
+__device__ __forceinline__ bool z_is_ambiguous(double tz) {
+    const double frac = fabs(tz - trunc(tz));        // exact
+    return !(fabs(frac - 0.5) > 9.5367431640625e-07);
+}
 __device__ __forceinline__ void fast_lane_init(FastLane& L, const double* __restrict__ pose, int P,
                                                int p, double lmax) {
     L.c = pose[4 * (size_t)P + p];
@@ -98,12 +104,11 @@ __device__ __forceinline__ void fast_lane_init(FastLane& L, const double* __rest
     L.ms = -L.s;
     L.cf = (float)L.c; L.sf = (float)L.s; L.msf = -L.sf;
     L.txf = (float)L.tx; L.tyf = (float)L.ty;
-    const float tzf = (float)L.tz;
-    L.zpf = rintf(tzf);
+    L.zpf = (float)round(L.tz);                      // exact: |tz| < 2^24
     const double tmax = fmax(fmax(fabs(L.tx), fabs(L.ty)), fabs(L.tz));
     // accept when |fp32 value - nearest integer| < thr = 0.5 - E (rounded down with margin)
     L.thr = (float)(0.5 - 2.5e-7 * (lmax + tmax) - 1.0e-7);
-    if (!(fabsf(tzf - L.zpf) < L.thr)) L.thr = -1.0f;
+    if (z_is_ambiguous(L.tz)) L.thr = -1.0f;
 }
 
 // Reference sequence S3P:745-747, 880, 85: flat index or a value >= elements.
@@ -183,6 +188,130 @@ __global__ __launch_bounds__(256) void k_measure_fast(
     partial[(size_t)blockIdx.y * P + p] = make_int2(sum, cnt);
 }
 
+// ------------------------------------------------------------------------------------------
+// K1 on the shared grid's GATHER LAYOUT ("z-octet": [Z/8][X][Y][Z%8], a second copy of the
+// grid kept by pf_api.hip next to the reference-order one). The 64 lanes of a wave are near-
+// identical hypotheses, so for one beam they land within a few cells of each other in X, Y and
+// Z; in the reference's z-fastest order every distinct (X, Y) is a different cache line (6.8
+// lines per wave-wide gather measured on the bench scene), in this layout a 64-B line holds an
+// 8 (Y) x 8 (Z) tile and the same gathers touch 3.2 lines. The texture path's cost is per line.
+//
+// Per evaluation: xh = x + 0.5 and yh = y + 0.5 in fp32 (two FMAs each), X = floor(xh) (one
+// v_cvt_flr), g = fract(xh). The fp32 value is within E = 2^-22 (Lmax + max|T| + 1) of the
+// reference's fp64 value plus 0.5, so when E <= g <= 1 - E on both axes, floor(xh) IS the
+// reference's round() (half-away ties are at g = 0, inside the rejected band). A wave with any
+// lane outside that band, or with any coordinate outside its axis range (where the reference's
+// flat-only bounds test S3P:882 lets indices alias into the neighbouring row), re-does those
+// beams with the reference fp64 sequence, and turns the flat index back into the cell it names.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned swz_addr(unsigned X, unsigned Y, unsigned Z, unsigned gy8,
+                                             unsigned kz) {
+    // ((Z>>3)*gx*gy + X*gy + Y)*8 + (Z&7) = (Z>>3)*(gx*gy*8 - 8) + X*gy*8 + (Y*8 + Z)
+    const unsigned t = __umul24(X, gy8) + ((Y << 3) + Z);
+    return __umul24(Z >> 3, kz) + t;
+}
+
+__device__ __forceinline__ int cvt_floor_i32(float x) {       // (int)floorf(x) in one instruction
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_measure_swz(
+        const double* __restrict__ sorted, int P, const uint8_t* __restrict__ shadow, PfSwz sw,
+        const PfBeamG* __restrict__ bg, const PfBeam* __restrict__ bd, int M, int bpc,
+        PfGridParams gp, double lmax, const int32_t* __restrict__ order,
+        int2* __restrict__ partial) {
+    const int lane_id = blockIdx.x * 256 + threadIdx.x;
+    if (lane_id >= P) return;
+    // lane constants: coalesced loads of the rows k_order_scatter wrote in lane order
+    const double c = sorted[lane_id], s = sorted[(size_t)P + lane_id];
+    const double tx = sorted[2 * (size_t)P + lane_id], ty = sorted[3 * (size_t)P + lane_id];
+    const double tz = sorted[4 * (size_t)P + lane_id];
+    const int p = order[lane_id];
+    const double ms = -s;
+    const float cf = (float)c, sf = (float)s, msf = -sf;
+    const float txh = (float)(tx + 0.5), tyh = (float)(ty + 0.5);
+    const int zp = (int)round(tz);                               // exact: |tz| < 2^24
+    const double tmax = fmax(fmax(fabs(tx), fabs(ty)), fabs(tz));
+    float E = (float)(2.5e-7 * (lmax + tmax + 1.0) + 1.0e-7);
+    if (z_is_ambiguous(tz)) E = 2.0f;                            // every beam of this wave: fp64
+    const float hi = (float)(1.0 - (double)E);
+    const unsigned gxu = sw.gx, gyu = sw.gy, gzu = sw.gz, gy8 = sw.gy8, kz = sw.kz;
+    const int j0 = blockIdx.y * bpc;
+    const int j1 = min(M, j0 + bpc);
+    int sum = 0, cnt = 0;
+    for (int j = j0; j < j1; j += PF_BEAM_GROUP) {
+        const PfBeamG g = bg[j / PF_BEAM_GROUP];     // wave-uniform: scalar loads
+        int X[PF_BEAM_GROUP], Y[PF_BEAM_GROUP], Z[PF_BEAM_GROUP];
+        float gmin = 0.5f, gmax = 0.5f;
+        bool okall = true;
+#pragma unroll
+        for (int k = 0; k < PF_BEAM_GROUP; ++k) {
+            const float xh = fmaf(cf, g.lx[k], fmaf(msf, g.ly[k], txh));
+            const float yh = fmaf(sf, g.lx[k], fmaf(cf, g.ly[k], tyh));
+            X[k] = cvt_floor_i32(xh); Y[k] = cvt_floor_i32(yh); Z[k] = g.lz[k] + zp;
+            const float fx = __builtin_amdgcn_fractf(xh), fy = __builtin_amdgcn_fractf(yh);
+            gmin = __builtin_fminf(gmin, __builtin_fminf(fx, fy));
+            gmax = __builtin_fmaxf(gmax, __builtin_fmaxf(fx, fy));
+            okall &= ((unsigned)X[k] < gxu) & ((unsigned)Y[k] < gyu) & ((unsigned)Z[k] < gzu);
+        }
+        const bool fine = (gmin >= E) & (gmax <= hi) & okall;
+        if (__builtin_expect(__all(fine), 1)) {
+            unsigned v[PF_BEAM_GROUP];
+#pragma unroll
+            for (int k = 0; k < PF_BEAM_GROUP; ++k)
+                v[k] = shadow[swz_addr((unsigned)X[k], (unsigned)Y[k], (unsigned)Z[k], gy8, kz)];
+            sum += (int)((v[0] + v[1]) + (v[2] + v[3]));         // S3P:887-888
+            cnt += PF_BEAM_GROUP;
+            continue;
+        }
+        // some lane is near a rounding boundary or off an axis: beam by beam
+        for (int k = 0; k < PF_BEAM_GROUP; ++k) {
+            const float xh = fmaf(cf, g.lx[k], fmaf(msf, g.ly[k], txh));
+            const float yh = fmaf(sf, g.lx[k], fmaf(cf, g.ly[k], tyh));
+            const float fx = __builtin_amdgcn_fractf(xh), fy = __builtin_amdgcn_fractf(yh);
+            unsigned xc = (unsigned)cvt_floor_i32(xh), yc = (unsigned)cvt_floor_i32(yh);
+            unsigned zc = (unsigned)(g.lz[k] + zp);
+            bool ok = (xc < gxu) & (yc < gyu) & (zc < gzu);
+            const bool good = (__builtin_fminf(fx, fy) >= E) & (__builtin_fmaxf(fx, fy) <= hi) & ok;
+            if (__any(!good)) {
+                // reference sequence S3P:745-747, 880, 85, then the cell the flat index names
+                const PfBeam d = bd[j + k];
+                const double Xd = round((c * d.lx + ms * d.ly) + tx);
+                const double Yd = round((s * d.lx + c * d.ly) + ty);
+                const double Zd = round(d.lz + tz);
+                const double fd = fma(Xd, gp.gyz, fma(Yd, gp.gzd, Zd));
+                ok = (fd >= 0.0) & (fd < gp.elements);                 // S3P:882
+                const unsigned f = ok ? (unsigned)fd : 0u;
+                xc = f / (gyu * gzu);
+                const unsigned r = f - xc * (gyu * gzu);
+                yc = r / gzu;
+                zc = r - yc * gzu;
+            }
+            const unsigned v = shadow[ok ? swz_addr(xc, yc, zc, gy8, kz) : 0u];
+            sum += ok ? (int)v : 0;
+            cnt += ok ? 1 : 0;
+        }
+    }
+    partial[(size_t)blockIdx.y * P + p] = make_int2(sum, cnt);
+}
+
+// reference order -> gather layout, one thread per octet (8 cells of one (X, Y) column)
+__global__ __launch_bounds__(256) void k_swz_build(const uint8_t* __restrict__ lin,
+                                                   uint2* __restrict__ shadow, PfSwz sw) {
+    const unsigned o = blockIdx.x * 256u + threadIdx.x;
+    const unsigned nzq = (sw.gz + 7u) / 8u, gxy = sw.gx * sw.gy;
+    if (o >= nzq * gxy) return;
+    const unsigned zq = o / gxy, rem = o - zq * gxy;              // rem = X*gy + Y
+    const uint8_t* src = lin + (size_t)rem * sw.gz + zq * 8u;
+    unsigned w[2] = {0u, 0u};
+#pragma unroll
+    for (unsigned k = 0; k < 8; ++k)
+        if (zq * 8u + k < sw.gz) w[k >> 2] |= (unsigned)src[k] << (8u * (k & 3u));
+    shadow[o] = make_uint2(w[0], w[1]);
+}
+
 __global__ __launch_bounds__(256) void k_reduce_scores(const int2* __restrict__ partial,
                                                        int n_chunks, int P,
                                                        int2* __restrict__ scores) {
@@ -245,6 +374,19 @@ hipError_t pfk_measure_fast(hipStream_t st, const double* pose, int P, const uin
     return hipGetLastError();
 }
 
+hipError_t pfk_measure_swz(hipStream_t st, const double* sorted, int P, const uint8_t* shadow,
+                           PfSwz sw, const PfBeamG* bg, const PfBeam* bd, int M, int n_chunks, int bpc,
+                           PfGridParams gp, double lmax, const int32_t* order, int2* partial) {
+    hipLaunchKernelGGL(k_measure_swz, dim3((P + 255) / 256, n_chunks), dim3(256), 0, st, sorted, P,
+                       shadow, sw, bg, bd, M, bpc, gp, lmax, order, partial);
+    return hipGetLastError();
+}
+hipError_t pfk_swz_build(hipStream_t st, const uint8_t* lin, uint8_t* shadow, PfSwz sw) {
+    const unsigned n = (sw.gz + 7u) / 8u * sw.gx * sw.gy;
+    hipLaunchKernelGGL(k_swz_build, dim3((n + 255u) / 256u), dim3(256), 0, st, lin, (uint2*)shadow, sw);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // Particle ordering for K1: a counting sort on a 15-bit key (6 bits of yaw in 0.002 rad steps,
 // 4 bits of x in half voxels, 5 bits of y in quarter voxels, each wrapping). It only decides which
@@ -252,17 +394,22 @@ hipError_t pfk_measure_fast(hipStream_t st, const double* pose, int P, const uin
 // order inside a bucket (atomic arrival order) cannot change any output.
 // ------------------------------------------------------------------------------------------
 #define ORDER_BUCKETS 32768
-__device__ inline int order_key(const double* __restrict__ pose, int P, int i) {
-    const int yq = (int)floor(pose[3 * (size_t)P + i] * 500.0) & 63;
-    const int xq = (int)floor(pose[6 * (size_t)P + i] * 2.0) & 15;
-    const int yy = (int)floor(pose[7 * (size_t)P + i] * 4.0) & 31;
-    return (yq << 9) | (xq << 5) | yy;
+__device__ inline int spread3(int v) {       // 5 bits -> every third bit
+    return (v & 1) | ((v & 2) << 2) | ((v & 4) << 4) | ((v & 8) << 6) | ((v & 16) << 8);
+}
+__device__ inline int order_key(const double* __restrict__ pose, int P, int i, PfOrderParams op) {
+    const int a = (int)floor(pose[3 * (size_t)P + i] * op.qa);
+    const int x = (int)floor(pose[6 * (size_t)P + i] * op.qx);
+    const int y = (int)floor(pose[7 * (size_t)P + i] * op.qy);
+    if (op.mode == 0) return ((a & 63) << 9) | ((x & 15) << 5) | (y & 31);
+    return (spread3(a & 31) << 2) | (spread3(x & 31) << 1) | spread3(y & 31);    // Morton
 }
 __global__ __launch_bounds__(256) void k_order_hist(const double* __restrict__ pose, int P,
-                                                    int32_t* __restrict__ keys, int32_t* hist) {
+                                                    int32_t* __restrict__ keys, int32_t* hist,
+                                                    PfOrderParams op) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    const int k = order_key(pose, P, i);
+    const int k = order_key(pose, P, i, op);
     keys[i] = k;
     atomicAdd(&hist[k], 1);
 }
@@ -296,17 +443,25 @@ __global__ __launch_bounds__(1024) void k_order_scan(int32_t* hist, int32_t* nex
         next_hist[wv * seg + k] = 0;
     }
 }
+// Besides order[], writes the pose rows K1 needs (cos, sin, x/res, y/res, z/res) in lane order:
+// sorted: double [5][P], so that K1's prologue is five coalesced loads with no indirection.
 __global__ __launch_bounds__(256) void k_order_scatter(const int32_t* __restrict__ keys, int P,
-                                                       int32_t* hist, int32_t* __restrict__ order) {
+                                                       int32_t* hist, int32_t* __restrict__ order,
+                                                       const double* __restrict__ pose,
+                                                       double* __restrict__ sorted) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    order[atomicAdd(&hist[keys[i]], 1)] = i;
+    const int r = atomicAdd(&hist[keys[i]], 1);
+    order[r] = i;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sorted[(size_t)k * P + r] = pose[(size_t)(4 + k) * P + i];
 }
 hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, int32_t* hist,
-                     int32_t* next_hist, int32_t* order) {
-    hipLaunchKernelGGL(k_order_hist, dim3((P + 255) / 256), dim3(256), 0, st, pose, P, keys, hist);
+                     int32_t* next_hist, int32_t* order, double* sorted, PfOrderParams op) {
+    hipLaunchKernelGGL(k_order_hist, dim3((P + 255) / 256), dim3(256), 0, st, pose, P, keys, hist, op);
     hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, st, hist, next_hist);
-    hipLaunchKernelGGL(k_order_scatter, dim3((P + 255) / 256), dim3(256), 0, st, keys, P, hist, order);
+    hipLaunchKernelGGL(k_order_scatter, dim3((P + 255) / 256), dim3(256), 0, st, keys, P, hist, order,
+                       pose, sorted);
     return hipGetLastError();
 }
 
@@ -359,6 +514,17 @@ __device__ inline long long flat_of(double rx, double ry, double rz, const PfUpd
     return (f < 0 || f >= up.elements) ? -1 : f;
 }
 
+// the same touch on the gather-layout copy of the shared grid (both copies see the same
+// order-independent function, so they stay identical)
+__device__ inline void shadow_touch(const PfUpdateParams& up, long long f, int inc, int clampv,
+                                    bool hit) {
+    if (!up.shadow) return;
+    const unsigned fu = (unsigned)f, gyz = (unsigned)(up.gy * up.gz);
+    const unsigned xc = fu / gyz, r = fu - xc * gyz, yc = r / (unsigned)up.gz;
+    const unsigned zc = r - yc * (unsigned)up.gz;
+    cell_touch(up.shadow, (long long)swz_addr(xc, yc, zc, up.swz_gy8, up.swz_kz), inc, clampv, hit, false);
+}
+
 __global__ __launch_bounds__(256) void k_update_hits(void* grid, const double* __restrict__ points,
                                                      int M, double* __restrict__ wpts,
                                                      PfUpdateParams up) {
@@ -377,6 +543,7 @@ __global__ __launch_bounds__(256) void k_update_hits(void* grid, const double* _
     const long long f = flat_of(wx * up.conv, wy * up.conv, wz * up.conv, up);
     if (f < 0) return;
     cell_touch(grid, f, up.hit_inc, up.hit_clamp, true, up.is_signed != 0);
+    shadow_touch(up, f, up.hit_inc, up.hit_clamp, true);
 }
 
 // One wave per ray; lane l takes steps j = 1+l, 65+l, ... (S3P:685: j = 1 .. n_it-1).
@@ -398,7 +565,10 @@ __global__ __launch_bounds__(256) void k_update_rays(void* grid, const double* _
         const double jd = (double)j;
         const long long f = flat_of((up.pos[0] + sx * jd) * up.conv, (up.pos[1] + sy * jd) * up.conv,
                                     (up.pos[2] + sz * jd) * up.conv, up);   // S3P:687-690
-        if (f >= 0) cell_touch(grid, f, up.miss_inc, up.miss_clamp, false, up.is_signed != 0);
+        if (f >= 0) {
+            cell_touch(grid, f, up.miss_inc, up.miss_clamp, false, up.is_signed != 0);
+            shadow_touch(up, f, up.miss_inc, up.miss_clamp, false);
+        }
     }
 }
 

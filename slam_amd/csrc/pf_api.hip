@@ -83,6 +83,14 @@ struct pf_handle {
     int n_points = 0, n_rays = 0;
     bool measured = false, weighted = false, have_u = false;
     bool exact = true;
+    // K3 and K4 are chains of small fixed-argument kernels: with SLAM_PF_GRAPH=1 each chain is
+    // captured once into a hipGraph and replayed (one launch instead of 5 and 8). Key = the
+    // pointer argument that can differ between calls. Off by default: measured on ROCm 7.2 the
+    // replay is SLOWER than the plain launches (K3 24.7 vs 18.0 us, K4 36.5 vs 28.7 us, step
+    // 167.6 vs 151.4 us; profiles/README.md).
+    struct GraphSlot { hipGraphExec_t exec = nullptr; const void* key = nullptr; bool bad = false; };
+    GraphSlot g_weights, g_resample;
+    bool use_graphs = false;
     // profiling
     bool profile = false;
     std::vector<EventPair> ev[PF_K_COUNT];
@@ -128,6 +136,32 @@ PfGridParams grid_params(const pf_handle* h) {
     gp.lo = h->cfg.map_lo;
     gp.hi = h->cfg.map_hi;
     return gp;
+}
+
+// Runs `launch` (which enqueues kernels on h->stream) through a cached graph.
+template <class F>
+hipError_t run_graph(pf_handle* h, pf_handle::GraphSlot& slot, const void* key, F&& launch) {
+    if (!h->use_graphs || slot.bad) return launch();
+    if (slot.exec && slot.key == key) return hipGraphLaunch(slot.exec, h->stream);
+    if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        slot.bad = true;
+        return launch();
+    }
+    const hipError_t el = launch();
+    hipGraph_t g = nullptr;
+    const hipError_t ec = hipStreamEndCapture(h->stream, &g);
+    hipError_t ei = hipErrorUnknown;
+    if (el == hipSuccess && ec == hipSuccess && g) ei = hipGraphInstantiate(&slot.exec, g, nullptr, nullptr, 0);
+    if (g) (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) {
+        (void)hipGetLastError();
+        slot.exec = nullptr; slot.bad = true;
+        return launch();
+    }
+    slot.key = key;
+    return hipGraphLaunch(slot.exec, h->stream);
 }
 
 struct Timed {
@@ -195,6 +229,8 @@ void pf_destroy(pf_handle* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : h->ev) for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (h->g_weights.exec) (void)hipGraphExecDestroy(h->g_weights.exec);
+    if (h->g_resample.exec) (void)hipGraphExecDestroy(h->g_resample.exec);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -303,6 +339,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->beams_occ, (size_t)c.max_beams + PF_BEAM_GROUP));
     CREATE_TRY(dalloc(&h->beams_occ_f, (size_t)c.max_beams + PF_BEAM_GROUP));
     CREATE_TRY(dalloc(&h->beams_occ_g, (size_t)c.max_beams / PF_BEAM_GROUP + 1));
+    if (const char* e = getenv("SLAM_PF_GRAPH")) h->use_graphs = atoi(e) != 0;
     if (const char* e = getenv("SLAM_PF_CHUNKS")) h->tune_chunks = atoi(e);
     if (const char* e = getenv("SLAM_PF_EXACT_MEASURE")) h->force_exact_measure = atoi(e);
     CREATE_TRY(dalloc(&h->partial, (size_t)h->max_chunks * P));
@@ -525,11 +562,15 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     return PF_OK;
 }
 
+// K1 lane order: Morton key over (yaw, x/res, y/res) in cells of 1/300 rad and 1/3 voxel; 4 bits
+// per axis sort 64-lane waves finely enough up to 64k particles per handle, 5 bits beyond.
+// SLAM_PF_ORDER=qa,qx,qy,mode,bits overrides (development knob).
 static PfOrderParams order_params(const pf_handle* h) {
-    PfOrderParams op{500.0, 2.0, 4.0, 0};
+    PfOrderParams op{300.0, 3.0, 3.0, 1, h->P <= 65536 ? 4 : 5};
     if (const char* e = getenv("SLAM_PF_ORDER")) {
-        double a, x, y; int m;
-        if (sscanf(e, "%lf,%lf,%lf,%d", &a, &x, &y, &m) == 4) op = PfOrderParams{a, x, y, m};
+        double a, x, y; int m, b;
+        if (sscanf(e, "%lf,%lf,%lf,%d,%d", &a, &x, &y, &m, &b) == 5 && (b == 4 || b == 5))
+            op = PfOrderParams{a, x, y, m, b};
     }
     return op;
 }
@@ -623,8 +664,10 @@ int pf_weights(pf_handle* h, const void* scores_global_dev) {
     const int2* sc = scores_global_dev ? (const int2*)scores_global_dev : h->scores;
     {
         Timed t(h, PF_K_WEIGHTS);
-        HIP_TRY(h, pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact, h->first,
-                               h->counters, h->rs));
+        HIP_TRY(h, run_graph(h, h->g_weights, sc, [&] {
+            return pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact, h->first,
+                               h->counters, h->rs);
+        }));
     }
     h->weighted = true;
     return PF_OK;
@@ -649,10 +692,12 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
         // FAST order: the parallel sum/scan differs from the sequential one by at most a few
         // Pg*2^-53 per boundary (all partial sums <= ~1); 8x that as the band.
         const double bound = h->exact ? 0.0 : 8.0 * (double)h->Pg * 1.1102230246251565e-16;
-        HIP_TRY(h, pfk_resample(h->stream, h->cdf, h->u, h->Pg, h->P, h->offset, bound, h->w, h->logw,
+        HIP_TRY(h, run_graph(h, h->g_resample, poses_global_dev, [&] {
+            return pfk_resample(h->stream, h->cdf, h->u, h->Pg, h->P, h->offset, bound, h->w, h->logw,
                                 h->pose, (const double*)poses_global_dev, h->slab ? h->maps : nullptr,
                                 h->slab, (unsigned long long)h->elements, h->draw, h->first, h->dup_anc,
-                                h->free_slot, h->slot_anc, h->best, h->counters, h->rs));
+                                h->free_slot, h->slot_anc, h->best, h->counters, h->rs);
+        }));
     }
     HIP_TRY(h, hipMemcpyAsync(h->h_result, h->counters, 4 * sizeof(unsigned long long),
                               hipMemcpyDeviceToHost, h->stream));

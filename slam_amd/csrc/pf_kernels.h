@@ -61,7 +61,8 @@ hipError_t pfk_measure_fast(hipStream_t st, const double* pose, int P, const uin
 #define PF_ORDER_BUCKETS 32768
 struct PfOrderParams {
     double qa, qx, qy;   // cells per radian of yaw / per voxel of x / per voxel of y
-    int32_t mode;        // 0: lexicographic yaw,x,y (6/4/5 bits)  1: Morton (5 bits each)
+    int32_t mode;        // 0: lexicographic yaw,x,y (6/4/5 bits)  1: Morton
+    int32_t bits;        // Morton: bits per axis, 4 (4096 buckets) or 5 (32768 buckets)
 };
 // sorted: double [5][P] = cos, sin, x/res, y/res, z/res in lane order (K1's prologue).
 hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, int32_t* hist,

@@ -4,6 +4,9 @@
 // would move round() across half-voxel boundaries. Where an fma() appears below it is on
 // integer-valued doubles whose exact result is representable, so fusing changes nothing.
 #include "pf_kernels.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include <limits.h>
 #include <math.h>
 
@@ -221,8 +224,9 @@ __global__ __launch_bounds__(256) void k_measure_swz(
         const double* __restrict__ sorted, int P, const uint8_t* __restrict__ shadow, PfSwz sw,
         const PfBeamG* __restrict__ bg, const PfBeam* __restrict__ bd, int M, int bpc,
         PfGridParams gp, double lmax, const int32_t* __restrict__ order,
-        int2* __restrict__ partial) {
+        int2* __restrict__ partial, unsigned long long* __restrict__ trace) {
     const int lane_id = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long t_start = trace ? wall_clock64() : 0;
     if (lane_id >= P) return;
     // lane constants: coalesced loads of the rows k_order_scatter wrote in lane order
     const double c = sorted[lane_id], s = sorted[(size_t)P + lane_id];
@@ -238,10 +242,19 @@ __global__ __launch_bounds__(256) void k_measure_swz(
     if (z_is_ambiguous(tz)) E = 2.0f;                            // every beam of this wave: fp64
     const float hi = (float)(1.0 - (double)E);
     const unsigned gxu = sw.gx, gyu = sw.gy, gzu = sw.gz, gy8 = sw.gy8, kz = sw.kz;
-    const int j0 = blockIdx.y * bpc;
-    const int j1 = min(M, j0 + bpc);
+    // Beam groups are dealt to the chunks (blockIdx.y) round-robin: the list is in the reference's
+    // x-major order (S3P:868), so contiguous chunks would differ in range and bearing, hence in
+    // cache lines per gather, and the launch would last as long as its most divergent chunk.
+    (void)bpc;
     int sum = 0, cnt = 0;
-    for (int j = j0; j < j1; j += PF_BEAM_GROUP) {
+    const unsigned long long t_loop = trace ? wall_clock64() + (E > 3.0f ? 1 : 0) : 0;
+    // The issue arbiter favours the oldest wave, which staggers the finish times of a launch
+    // that is one residency deep and leaves the CUs half empty at the end. Waves in the first
+    // half of their beams therefore run at a higher priority than waves in the second half.
+    const int j_half = M / 2;
+    __builtin_amdgcn_s_setprio(2);
+    for (int j = blockIdx.y * PF_BEAM_GROUP; j < M; j += gridDim.y * PF_BEAM_GROUP) {
+        if (j >= j_half) __builtin_amdgcn_s_setprio(0);
         const PfBeamG g = bg[j / PF_BEAM_GROUP];     // wave-uniform: scalar loads
         int X[PF_BEAM_GROUP], Y[PF_BEAM_GROUP], Z[PF_BEAM_GROUP];
         float gmin = 0.5f, gmax = 0.5f;
@@ -295,6 +308,11 @@ __global__ __launch_bounds__(256) void k_measure_swz(
         }
     }
     partial[(size_t)blockIdx.y * P + p] = make_int2(sum, cnt);
+    if (trace && (threadIdx.x & 63) == 0) {          // development aid: per-wave timeline
+        const size_t w = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+        trace[4 * w + 0] = t_start; trace[4 * w + 1] = t_loop; trace[4 * w + 2] = wall_clock64();
+        trace[4 * w + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
 }
 
 // reference order -> gather layout, one thread per octet (8 cells of one (X, Y) column)
@@ -377,8 +395,24 @@ hipError_t pfk_measure_fast(hipStream_t st, const double* pose, int P, const uin
 hipError_t pfk_measure_swz(hipStream_t st, const double* sorted, int P, const uint8_t* shadow,
                            PfSwz sw, const PfBeamG* bg, const PfBeam* bd, int M, int n_chunks, int bpc,
                            PfGridParams gp, double lmax, const int32_t* order, int2* partial) {
+    // SLAM_PF_K1_TRACE=<file>: development aid, dumps {start, loop start, end, HW_ID} per wave
+    static unsigned long long* trace = nullptr;
+    const char* trace_path = getenv("SLAM_PF_K1_TRACE");
+    const size_t trace_n = (size_t)((P + 255) / 256) * n_chunks * 16;
+    if (trace_path) {
+        if (trace) (void)hipFree(trace);
+        if (hipMalloc((void**)&trace, 8 * trace_n) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(trace, 0, 8 * trace_n, st);
+    }
     hipLaunchKernelGGL(k_measure_swz, dim3((P + 255) / 256, n_chunks), dim3(256), 0, st, sorted, P,
-                       shadow, sw, bg, bd, M, bpc, gp, lmax, order, partial);
+                       shadow, sw, bg, bd, M, bpc, gp, lmax, order, partial, trace_path ? trace : nullptr);
+    if (trace_path) {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> hbuf(trace_n);
+        (void)hipMemcpy(hbuf.data(), trace, 8 * trace_n, hipMemcpyDeviceToHost);
+        if (FILE* fp = fopen(trace_path, "wb")) { fwrite(hbuf.data(), 8, trace_n, fp); fclose(fp); }
+        (void)hipFree(trace); trace = nullptr;
+    }
     return hipGetLastError();
 }
 hipError_t pfk_swz_build(hipStream_t st, const uint8_t* lin, uint8_t* shadow, PfSwz sw) {
@@ -393,7 +427,6 @@ hipError_t pfk_swz_build(hipStream_t st, const uint8_t* lin, uint8_t* shadow, Pf
 // particles share a wave; every per-particle result is independent of it, so the arbitrary
 // order inside a bucket (atomic arrival order) cannot change any output.
 // ------------------------------------------------------------------------------------------
-#define ORDER_BUCKETS 32768
 __device__ inline int spread3(int v) {       // 5 bits -> every third bit
     return (v & 1) | ((v & 2) << 2) | ((v & 4) << 4) | ((v & 8) << 6) | ((v & 16) << 8);
 }
@@ -402,7 +435,8 @@ __device__ inline int order_key(const double* __restrict__ pose, int P, int i, P
     const int x = (int)floor(pose[6 * (size_t)P + i] * op.qx);
     const int y = (int)floor(pose[7 * (size_t)P + i] * op.qy);
     if (op.mode == 0) return ((a & 63) << 9) | ((x & 15) << 5) | (y & 31);
-    return (spread3(a & 31) << 2) | (spread3(x & 31) << 1) | spread3(y & 31);    // Morton
+    const int m = (1 << op.bits) - 1;                                          // Morton
+    return (spread3(a & m) << 2) | (spread3(x & m) << 1) | spread3(y & m);
 }
 __global__ __launch_bounds__(256) void k_order_hist(const double* __restrict__ pose, int P,
                                                     int32_t* __restrict__ keys, int32_t* hist,
@@ -413,34 +447,39 @@ __global__ __launch_bounds__(256) void k_order_hist(const double* __restrict__ p
     keys[i] = k;
     atomicAdd(&hist[k], 1);
 }
-// exclusive scan of hist in place; zeroes the buffer the NEXT sort will count into.
-// One workgroup of 16 waves; wave w owns the contiguous segment [w*2048, (w+1)*2048) and walks
-// it 64 entries at a time (coalesced), so the scan is 2 x 32 wave-iterations, not a per-thread
-// strided walk.
+// exclusive scan of hist[0 .. 1024*E) in place; zeroes the buffer the NEXT sort will count into.
+// One workgroup of 1024 threads, E = 4 or 32 consecutive entries per thread (int4 loads).
+template <int E>
 __global__ __launch_bounds__(1024) void k_order_scan(int32_t* hist, int32_t* next_hist) {
     __shared__ int tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int seg = ORDER_BUCKETS / 16;
-    int32_t* h = hist + wv * seg;
+    int4* h4 = (int4*)hist + (size_t)tid * (E / 4);
+    int4* z4 = (int4*)next_hist + (size_t)tid * (E / 4);
+    int4 v[E / 4];
+#pragma unroll
+    for (int k = 0; k < E / 4; ++k) v[k] = h4[k];
     int sum = 0;
-    for (int k = lane; k < seg; k += 64) sum += h[k];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    if (lane == 0) tot[wv] = sum;
+    for (int k = 0; k < E / 4; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) tot[wv] = inc;
     __syncthreads();
-    int carry = 0;
-    for (int k = 0; k < wv; ++k) carry += tot[k];
-    for (int k = lane; k < seg; k += 64) {
-        const int v = h[k];
-        int inc = v;
+    int run = inc - sum;
+    for (int k = 0; k < wv; ++k) run += tot[k];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        h[k] = carry + inc - v;
-        carry += __shfl(inc, 63, 64);
-        next_hist[wv * seg + k] = 0;
+    for (int k = 0; k < E / 4; ++k) {
+        int4 o;
+        o.x = run; run += v[k].x;
+        o.y = run; run += v[k].y;
+        o.z = run; run += v[k].z;
+        o.w = run; run += v[k].w;
+        h4[k] = o;
+        z4[k] = make_int4(0, 0, 0, 0);
     }
 }
 // Besides order[], writes the pose rows K1 needs (cos, sin, x/res, y/res, z/res) in lane order:
@@ -459,7 +498,10 @@ __global__ __launch_bounds__(256) void k_order_scatter(const int32_t* __restrict
 hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, int32_t* hist,
                      int32_t* next_hist, int32_t* order, double* sorted, PfOrderParams op) {
     hipLaunchKernelGGL(k_order_hist, dim3((P + 255) / 256), dim3(256), 0, st, pose, P, keys, hist, op);
-    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, st, hist, next_hist);
+    if (op.mode != 0 && op.bits == 4)
+        hipLaunchKernelGGL(k_order_scan<4>, dim3(1), dim3(1024), 0, st, hist, next_hist);
+    else
+        hipLaunchKernelGGL(k_order_scan<32>, dim3(1), dim3(1024), 0, st, hist, next_hist);
     hipLaunchKernelGGL(k_order_scatter, dim3((P + 255) / 256), dim3(256), 0, st, keys, P, hist, order,
                        pose, sorted);
     return hipGetLastError();

@@ -14,12 +14,14 @@
 #include "pf_kernels.h"
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 
 #define WAVE 64
 #define WG 1024
 #define TILE 4096
 #define NB 256                   // threads per block of the multi-block kernels
 #define NEVER_DRAWN 0x7f7f7f7f   // "nobody drew this slot": larger than any slot number
+#define PF_MID_MAX 16384         // limit of the one-workgroup forms k3_mid / k4_mid
 
 // prm[] layout (device doubles)
 #define PRM_K99 0      // 0.99 * smallest sum (S3P:928)
@@ -65,6 +67,34 @@ __device__ inline double block_max(double v, double* sh) {
     for (int k = 1; k < nw; ++k) r = fmax(r, sh[k]);
     return r;
 }
+// The same for one 256-thread group of a larger workgroup: sh4 = this group's 4 doubles, wv4 =
+// the wave's index inside the group. Every thread of the WORKGROUP must call it (barriers).
+// Same shape as block_sum/block_max in a 256-thread block, so the results are bit-identical.
+__device__ inline double group_sum(double v, double* sh4, int lane, int wv4) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh4[wv4] = v;
+    __syncthreads();
+    double r = 0;
+    for (int k = 0; k < NB / WAVE; ++k) r += sh4[k];
+    return r;
+}
+__device__ inline double group_max(double v, double* sh4, int lane, int wv4) {
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) sh4[wv4] = v;
+    __syncthreads();
+    double r = sh4[0];
+    for (int k = 1; k < NB / WAVE; ++k) r = fmax(r, sh4[k]);
+    return r;
+}
+__device__ inline int ld_agent(const int32_t* p) {     // a value other waves change with atomics
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline unsigned long long ld_agent(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Inclusive wave scan (Kogge-Stone over the 64 lanes), fixed shape.
 __device__ inline double wave_scan(double v) {
     const int lane = threadIdx.x & 63;
@@ -186,15 +216,14 @@ __global__ __launch_bounds__(WG) void k_weights_exact(const int2* __restrict__ s
 __global__ __launch_bounds__(WG) void k_cdf_exact_if(const double* w, int Pg, double* cdf,
                                                      const unsigned long long* counters) {
     __shared__ double tile[TILE];
-    if (counters[1] == 0) return;
+    if (ld_agent(&counters[1]) == 0) return;
     seq_cdf(w, Pg, cdf, tile);
 }
 
 // ------------------------------------------------------------------------------------------
 // FAST order: K3 as four kernels.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k3_min(const int2* __restrict__ scores, int Pg, double* prm) {
-    __shared__ int shi[WG / WAVE];
+__device__ inline void d3_min(const int2* __restrict__ scores, int Pg, double* prm, int* shi) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int m = INT_MAX;
     for (int g = tid; g < Pg; g += WG) m = min(m, scores[g].x);
@@ -212,35 +241,41 @@ __global__ __launch_bounds__(WG) void k3_min(const int2* __restrict__ scores, in
         prm[PRM_LOGN] = log(n_match);
     }
 }
+__global__ __launch_bounds__(WG) void k3_min(const int2* __restrict__ scores, int Pg, double* prm) {
+    __shared__ int shi[WG / WAVE];
+    d3_min(scores, Pg, prm, shi);
+}
 
 // raw weights + per-block partials: bsum[b] = sum of the block's raw weights (wave shuffle tree,
 // then the 4 wave totals in order), (bmax[b], bse[b]) = block max of l and sum of exp(l - bmax).
-__global__ __launch_bounds__(NB) void k3_raw(const int2* __restrict__ scores, int Pg, double* w,
-                                             double* __restrict__ lbuf,
-                                             const double* __restrict__ prm, double* bsum,
-                                             double* bmax, double* bse) {
-    __shared__ double sh[NB / WAVE];
-    const int g = blockIdx.x * NB + threadIdx.x;
+// vb = the 256-particle block, lt = thread inside it, sh4 = 4 doubles of LDS for this block.
+__device__ inline void d3_raw(int vb, int lt, double* sh4, const int2* __restrict__ scores, int Pg,
+                              double* w, double* __restrict__ lbuf, const double* prm, double* bsum,
+                              double* bmax, double* bse) {
+    const int g = vb * NB + lt, lane = lt & 63, wv4 = lt >> 6;
     double raw = 0, l = -INFINITY;
     if (g < Pg) {
         raw_weight(w[g], scores[g].x, prm[PRM_K99], prm[PRM_N], prm[PRM_LOGN], raw, l);
         w[g] = raw;
         lbuf[g] = l;
     }
-    const double s = block_sum(raw, sh);
-    const double m = block_max(l, sh);
-    const double e = block_sum((g < Pg && l > -INFINITY) ? exp(l - m) : 0.0, sh);
-    if (threadIdx.x == 0) { bsum[blockIdx.x] = s; bmax[blockIdx.x] = m; bse[blockIdx.x] = e; }
+    const double s = group_sum(raw, sh4, lane, wv4);
+    const double m = group_max(l, sh4, lane, wv4);
+    const double e = group_sum((g < Pg && l > -INFINITY) ? exp(l - m) : 0.0, sh4, lane, wv4);
+    if (lt == 0 && g < Pg) { bsum[vb] = s; bmax[vb] = m; bse[vb] = e; }
+}
+__global__ __launch_bounds__(NB) void k3_raw(const int2* __restrict__ scores, int Pg, double* w,
+                                             double* __restrict__ lbuf,
+                                             const double* __restrict__ prm, double* bsum,
+                                             double* bmax, double* bse) {
+    __shared__ double sh[NB / WAVE];
+    d3_raw(blockIdx.x, threadIdx.x, sh, scores, Pg, w, lbuf, prm, bsum, bmax, bse);
 }
 
 // One workgroup: S = sum of bsum (thread t adds blocks t, t+1024, ... then the fixed tree),
 // exclusive scan of bsum into boff, global max / log-sum-exp.
-__global__ __launch_bounds__(WG) void k3_combine(int nb, const double* __restrict__ bsum,
-                                                 const double* __restrict__ bmax,
-                                                 const double* __restrict__ bse, double* boff,
-                                                 double* prm) {
-    __shared__ double sh[WG / WAVE];
-    __shared__ double tile[WG];
+__device__ inline void d3_combine(int nb, const double* bsum, const double* bmax, const double* bse,
+                                  double* boff, double* prm, double* sh) {
     const int tid = threadIdx.x;
     // contiguous segment per thread so that the scan is a scan
     const int seg = (nb + WG - 1) / WG;
@@ -263,14 +298,42 @@ __global__ __launch_bounds__(WG) void k3_combine(int nb, const double* __restric
     double se = 0;
     for (int k = b; k < e; ++k) se += bmax[k] > -INFINITY ? bse[k] * exp(bmax[k] - gmax) : 0.0;
     se = block_sum(se, sh);
-    (void)tile;
     if (tid == 0) {
         prm[PRM_S] = total;
         prm[PRM_LSE] = gmax + log(se);
     }
 }
+__global__ __launch_bounds__(WG) void k3_combine(int nb, const double* __restrict__ bsum,
+                                                 const double* __restrict__ bmax,
+                                                 const double* __restrict__ bse, double* boff,
+                                                 double* prm) {
+    __shared__ double sh[WG / WAVE];
+    d3_combine(nb, bsum, bmax, bse, boff, prm, sh);
+}
 
 // normalise, log-weights, CDF: cdf[i+1] = (boff[block] + inclusive scan of raw inside the block) / S.
+__device__ inline void d3_norm(int vb, int lt, double* sh4, int Pg, double* w, const double* lbuf,
+                               float* __restrict__ logw, const double* prm, const double* boff,
+                               double* cdf, int32_t* __restrict__ first,
+                               unsigned long long* counters) {
+    const int g = vb * NB + lt, lane = lt & 63, wv4 = lt >> 6;
+    const double S = prm[PRM_S];
+    const double raw = g < Pg ? w[g] : 0.0;
+    const double inc = wave_scan(raw);
+    __syncthreads();
+    if (lane == 63) sh4[wv4] = inc;
+    __syncthreads();
+    double woff = 0;
+    for (int k = 0; k < wv4; ++k) woff += sh4[k];
+    if (g < Pg) {
+        w[g] = raw / S;                                     // S3P:936
+        logw[g] = (float)(lbuf[g] - prm[PRM_LSE]);
+        cdf[g + 1] = (boff[vb] + (woff + inc)) / S;
+        first[g] = NEVER_DRAWN;                             // K4's first-occurrence table
+    }
+    if (g == 0) cdf[0] = 0;
+    if (g < 3) counters[g] = 0;                             // K4's counters start at zero
+}
 __global__ __launch_bounds__(NB) void k3_norm(int Pg, double* w, const double* __restrict__ lbuf,
                                               float* __restrict__ logw,
                                               const double* __restrict__ prm,
@@ -278,23 +341,29 @@ __global__ __launch_bounds__(NB) void k3_norm(int Pg, double* w, const double* _
                                               int32_t* __restrict__ first,
                                               unsigned long long* counters) {
     __shared__ double sh[NB / WAVE];
-    const int g = blockIdx.x * NB + threadIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const double S = prm[PRM_S];
-    const double raw = g < Pg ? w[g] : 0.0;
-    const double inc = wave_scan(raw);
-    if (lane == 63) sh[wv] = inc;
+    d3_norm(blockIdx.x, threadIdx.x, sh, Pg, w, lbuf, logw, prm, boff, cdf, first, counters);
+}
+
+// K3 in ONE workgroup for up to PF_MID_MAX particles: the same four stages on the same 256-
+// particle blocks (four at a time), barriers instead of kernel boundaries. Bit-identical to the
+// four-kernel chain; one launch instead of four.
+__global__ __launch_bounds__(WG) void k3_mid(const int2* __restrict__ scores, int Pg, double* w,
+                                             double* lbuf, float* __restrict__ logw, double* cdf,
+                                             int32_t* __restrict__ first,
+                                             unsigned long long* counters, PfResampleScratch sc) {
+    __shared__ double sh[WG / WAVE];
+    __shared__ int shi[WG / WAVE];
+    const int tid = threadIdx.x, grp = tid >> 8, lt = tid & (NB - 1);
+    const int nb = (Pg + NB - 1) / NB;
+    d3_min(scores, Pg, sc.prm, shi);
     __syncthreads();
-    double woff = 0;
-    for (int k = 0; k < wv; ++k) woff += sh[k];
-    if (g < Pg) {
-        w[g] = raw / S;                                     // S3P:936
-        logw[g] = (float)(lbuf[g] - prm[PRM_LSE]);
-        cdf[g + 1] = (boff[blockIdx.x] + (woff + inc)) / S;
-        first[g] = NEVER_DRAWN;                             // K4's first-occurrence table
-    }
-    if (g == 0) cdf[0] = 0;
-    if (g < 3) counters[g] = 0;                             // K4's counters start at zero
+    for (int vb0 = 0; vb0 < nb; vb0 += WG / NB)
+        d3_raw(vb0 + grp, lt, sh + 4 * grp, scores, Pg, w, lbuf, sc.prm, sc.bsum, sc.bmax, sc.bse);
+    __syncthreads();
+    d3_combine(nb, sc.bsum, sc.bmax, sc.bse, sc.boff, sc.prm, sh);
+    __syncthreads();
+    for (int vb0 = 0; vb0 < nb; vb0 += WG / NB)
+        d3_norm(vb0 + grp, lt, sh + 4 * grp, Pg, w, lbuf, logw, sc.prm, sc.boff, cdf, first, counters);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -315,11 +384,8 @@ __device__ inline int search_draw(const double* __restrict__ cdf, double ui, int
     pos = lo;
     return hit ? lo - 1 : i;
 }
-__global__ __launch_bounds__(NB) void k_search(const double* __restrict__ cdf,
-                                               const double* __restrict__ u, int Pg, double bound,
-                                               int32_t* __restrict__ draw,
-                                               unsigned long long* counters) {
-    const int i = blockIdx.x * NB + threadIdx.x;
+__device__ inline void d_search(int i, const double* cdf, const double* __restrict__ u, int Pg,
+                                double bound, int32_t* draw, unsigned long long* counters) {
     if (i >= Pg) return;
     const double ui = u[i];
     bool hit; int lo;
@@ -331,17 +397,21 @@ __global__ __launch_bounds__(NB) void k_search(const double* __restrict__ cdf,
         if (amb) atomicAdd(&counters[1], 1ull);
     }
 }
+__global__ __launch_bounds__(NB) void k_search(const double* __restrict__ cdf,
+                                               const double* __restrict__ u, int Pg, double bound,
+                                               int32_t* __restrict__ draw,
+                                               unsigned long long* counters) {
+    d_search(blockIdx.x * NB + threadIdx.x, cdf, u, Pg, bound, draw, counters);
+}
 
 // first[a] = position of the first draw of ancestor a. When the FAST-order search flagged
 // ambiguous draws, k_cdf_exact_if has rebuilt the CDF in sequential order in between and every
 // draw is searched again here (no-hits recounted in counters[2]).
-__global__ __launch_bounds__(NB) void k_first(const double* __restrict__ cdf,
-                                              const double* __restrict__ u, int32_t* draw, int Pg,
-                                              int32_t* first, unsigned long long* counters) {
-    const int i = blockIdx.x * NB + threadIdx.x;
+__device__ inline void d_first(int i, const double* cdf, const double* __restrict__ u, int32_t* draw,
+                               int Pg, int32_t* first, unsigned long long* counters) {
     if (i >= Pg) return;
     int a = draw[i];
-    if (counters[1] != 0) {
+    if (ld_agent(&counters[1]) != 0) {
         bool hit; int lo;
         a = search_draw(cdf, u[i], i, Pg, hit, lo);
         draw[i] = a;
@@ -349,36 +419,46 @@ __global__ __launch_bounds__(NB) void k_first(const double* __restrict__ cdf,
     }
     atomicMin(&first[a], i);
 }
+__global__ __launch_bounds__(NB) void k_first(const double* __restrict__ cdf,
+                                              const double* __restrict__ u, int32_t* draw, int Pg,
+                                              int32_t* first, unsigned long long* counters) {
+    d_first(blockIdx.x * NB + threadIdx.x, cdf, u, draw, Pg, first, counters);
+}
 
 // S3P:782-802 in parallel form. A draw is a duplicate when its ancestor was drawn earlier
 // (first[a] != i); slot j is free when nobody drew it. The k-th duplicate (draw order) goes to
-// the k-th free slot (ascending); drawn slots keep themselves. Three kernels: per-block counts,
+// the k-th free slot (ascending); drawn slots keep themselves. Three stages: per-block counts,
 // scan of the counts, ranked scatter; then the fill.
+// (vb, lt, sd4/sf4: the 256-particle block, the thread in it, 4 ints of LDS each for the block)
+__device__ inline void d4_count(int vb, int lt, int* sd4, int* sf4, const int32_t* draw, int Pg,
+                                const int32_t* first, int2* bcnt) {
+    const int i = vb * NB + lt, lane = lt & 63, wv4 = lt >> 6;
+    const int isd = i < Pg && ld_agent(&first[draw[i]]) != i;
+    const int isf = i < Pg && ld_agent(&first[i]) == NEVER_DRAWN;
+    const int nd = __popcll(__ballot(isd)), nf = __popcll(__ballot(isf));
+    __syncthreads();
+    if (lane == 0) { sd4[wv4] = nd; sf4[wv4] = nf; }
+    __syncthreads();
+    if (lt == 0 && i < Pg) {
+        int a = 0, b = 0;
+        for (int k = 0; k < NB / WAVE; ++k) { a += sd4[k]; b += sf4[k]; }
+        bcnt[vb] = make_int2(a, b);
+    }
+}
 __global__ __launch_bounds__(NB) void k4_count(const int32_t* __restrict__ draw, int Pg,
                                                const int32_t* __restrict__ first, int2* bcnt) {
     __shared__ int sd[NB / WAVE], sf[NB / WAVE];
-    const int i = blockIdx.x * NB + threadIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int isd = i < Pg && first[draw[i]] != i;
-    const int isf = i < Pg && first[i] == NEVER_DRAWN;
-    const int nd = __popcll(__ballot(isd)), nf = __popcll(__ballot(isf));
-    if (lane == 0) { sd[wv] = nd; sf[wv] = nf; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int a = 0, b = 0;
-        for (int k = 0; k < NB / WAVE; ++k) { a += sd[k]; b += sf[k]; }
-        bcnt[blockIdx.x] = make_int2(a, b);
-    }
+    d4_count(blockIdx.x, threadIdx.x, sd, sf, draw, Pg, first, bcnt);
 }
-__global__ __launch_bounds__(WG) void k4_scan(int nb, const int2* __restrict__ bcnt, int2* boff,
-                                              int32_t* ndup_out) {
-    __shared__ int sd[WG / WAVE], sf[WG / WAVE];
+__device__ inline void d4_scan(int nb, const int2* bcnt, int2* boff, int32_t* ndup_out, int* sd,
+                               int* sf) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int seg = (nb + WG - 1) / WG;
     const int b = tid * seg, e = min(nb, b + seg);
     int ld = 0, lf = 0;
     for (int k = b; k < e; ++k) { ld += bcnt[k].x; lf += bcnt[k].y; }
     const int id = wave_scan_i(ld), jf = wave_scan_i(lf);
+    __syncthreads();
     if (lane == 63) { sd[wv] = id; sf[wv] = jf; }
     __syncthreads();
     int od = 0, of = 0;
@@ -387,6 +467,31 @@ __global__ __launch_bounds__(WG) void k4_scan(int nb, const int2* __restrict__ b
     for (int k = b; k < e; ++k) { boff[k] = make_int2(rd, rf); rd += bcnt[k].x; rf += bcnt[k].y; }
     if (tid == WG - 1) *ndup_out = od + id;
 }
+__global__ __launch_bounds__(WG) void k4_scan(int nb, const int2* __restrict__ bcnt, int2* boff,
+                                              int32_t* ndup_out) {
+    __shared__ int sd[WG / WAVE], sf[WG / WAVE];
+    d4_scan(nb, bcnt, boff, ndup_out, sd, sf);
+}
+__device__ inline void d4_scatter(int vb, int lt, int* sd4, int* sf4, const int32_t* draw, int Pg,
+                                  const int32_t* first, const int2* boff, int32_t* dup_anc,
+                                  int32_t* slot_anc) {
+    const int i = vb * NB + lt, lane = lt & 63, wv4 = lt >> 6;
+    const int a = i < Pg ? draw[i] : 0;
+    const int isd = i < Pg && ld_agent(&first[a]) != i;
+    const int isf = i < Pg && ld_agent(&first[i]) == NEVER_DRAWN;
+    const unsigned long long md = __ballot(isd), mf = __ballot(isf);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    __syncthreads();
+    if (lane == 0) { sd4[wv4] = __popcll(md); sf4[wv4] = __popcll(mf); }
+    __syncthreads();
+    if (i >= Pg) return;                                    // after the last barrier
+    int od = boff[vb].x, of = boff[vb].y;
+    for (int k = 0; k < wv4; ++k) { od += sd4[k]; of += sf4[k]; }
+    if (isd) dup_anc[od + __popcll(md & below)] = a;
+    // a free slot takes the duplicate of its own rank; the apply stage resolves -1-rank -> dup_anc[rank]
+    if (isf) slot_anc[i] = -1 - (of + __popcll(mf & below));
+    else slot_anc[i] = i;
+}
 __global__ __launch_bounds__(NB) void k4_scatter(const int32_t* __restrict__ draw, int Pg,
                                                  const int32_t* __restrict__ first,
                                                  const int2* __restrict__ boff,
@@ -394,35 +499,18 @@ __global__ __launch_bounds__(NB) void k4_scatter(const int32_t* __restrict__ dra
                                                  int32_t* __restrict__ free_slot,
                                                  int32_t* __restrict__ slot_anc) {
     __shared__ int sd[NB / WAVE], sf[NB / WAVE];
-    const int i = blockIdx.x * NB + threadIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int a = i < Pg ? draw[i] : 0;
-    const int isd = i < Pg && first[a] != i;
-    const int isf = i < Pg && first[i] == NEVER_DRAWN;
-    const unsigned long long md = __ballot(isd), mf = __ballot(isf);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (lane == 0) { sd[wv] = __popcll(md); sf[wv] = __popcll(mf); }
-    __syncthreads();
-    int od = boff[blockIdx.x].x, of = boff[blockIdx.x].y;
-    for (int k = 0; k < wv; ++k) { od += sd[k]; of += sf[k]; }
-    if (isd) dup_anc[od + __popcll(md & below)] = a;
-    // a free slot takes the duplicate of its own rank; k4_apply resolves -1-rank -> dup_anc[rank]
-    if (isf) slot_anc[i] = -1 - (of + __popcll(mf & below));
-    else if (i < Pg) slot_anc[i] = i;
+    (void)free_slot;
+    d4_scatter(blockIdx.x, threadIdx.x, sd, sf, draw, Pg, first, boff, dup_anc, slot_anc);
 }
 // S3P:805-812 + the first stage of S3P:814-820. Sources are slots that keep themselves, so the
-// in-place parallel copy reads nothing that this launch writes. Per block: the first index of
+// in-place parallel copy reads nothing that this stage writes. Per block: the first index of
 // the block's strict maximum of the NEW weights above 0.
-// POSE: the handle holds all particles (one GPU), the pose rows move in the same launch.
+// POSE: the handle holds all particles (one GPU), the pose rows move in the same stage.
 template <bool POSE>
-__global__ __launch_bounds__(NB) void k4_apply(int32_t* __restrict__ slot_anc,
-                                               const int32_t* __restrict__ dup_anc, int Pg,
-                                               double* w, float* logw, double* pose,
-                                               double* bbest_v, int32_t* bbest_i) {
-    __shared__ double sv[NB / WAVE];
-    __shared__ int si[NB / WAVE];
-    const int g = blockIdx.x * NB + threadIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+__device__ inline void d4_apply(int vb, int lt, double* sv4, int* si4, int32_t* slot_anc,
+                                const int32_t* dup_anc, int Pg, double* w, float* logw, double* pose,
+                                double* bbest_v, int32_t* bbest_i) {
+    const int g = vb * NB + lt, lane = lt & 63, wv4 = lt >> 6;
     double v = 0.0;
     int idx = -1;
     if (g < Pg) {
@@ -445,26 +533,34 @@ __global__ __launch_bounds__(NB) void k4_apply(int32_t* __restrict__ slot_anc,
         const int oi = __shfl_down(idx, o, WAVE);
         if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
     }
-    if (lane == 0) { sv[wv] = v; si[wv] = idx; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (lane == 0) { sv4[wv4] = v; si4[wv4] = idx; }
+    __syncthreads();
+    if (lt == 0 && g < Pg) {
         for (int k = 1; k < NB / WAVE; ++k)
-            if (si[k] >= 0 && (idx < 0 || sv[k] > v || (sv[k] == v && si[k] < idx))) { v = sv[k]; idx = si[k]; }
-        bbest_v[blockIdx.x] = v;
-        bbest_i[blockIdx.x] = idx;
+            if (si4[k] >= 0 && (idx < 0 || sv4[k] > v || (sv4[k] == v && si4[k] < idx))) { v = sv4[k]; idx = si4[k]; }
+        bbest_v[vb] = v;
+        bbest_i[vb] = idx;
     }
 }
-__global__ __launch_bounds__(WG) void k4_argmax(int nb, const double* __restrict__ bbest_v,
-                                                const int32_t* __restrict__ bbest_i,
-                                                int32_t* best_inout) {
-    __shared__ double sv[WG];
-    __shared__ int si[WG];
+template <bool POSE>
+__global__ __launch_bounds__(NB) void k4_apply(int32_t* __restrict__ slot_anc,
+                                               const int32_t* __restrict__ dup_anc, int Pg,
+                                               double* w, float* logw, double* pose,
+                                               double* bbest_v, int32_t* bbest_i) {
+    __shared__ double sv[NB / WAVE];
+    __shared__ int si[NB / WAVE];
+    d4_apply<POSE>(blockIdx.x, threadIdx.x, sv, si, slot_anc, dup_anc, Pg, w, logw, pose, bbest_v, bbest_i);
+}
+__device__ inline void d4_argmax(int nb, const double* bbest_v, const int32_t* bbest_i,
+                                 int32_t* best_inout, double* sv, int* si) {
     const int tid = threadIdx.x;
     double v = 0.0; int idx = -1;
     for (int k = tid; k < nb; k += WG) {
         const int oi = bbest_i[k]; const double ov = bbest_v[k];
         if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
     }
+    __syncthreads();
     sv[tid] = v; si[tid] = idx;
     __syncthreads();
     for (int o = WG / 2; o > 0; o >>= 1) {
@@ -477,6 +573,50 @@ __global__ __launch_bounds__(WG) void k4_argmax(int nb, const double* __restrict
         __syncthreads();
     }
     if (tid == 0 && si[0] >= 0) *best_inout = si[0];        // otherwise the previous index stays
+}
+__global__ __launch_bounds__(WG) void k4_argmax(int nb, const double* __restrict__ bbest_v,
+                                                const int32_t* __restrict__ bbest_i,
+                                                int32_t* best_inout) {
+    __shared__ double sv[WG];
+    __shared__ int si[WG];
+    d4_argmax(nb, bbest_v, bbest_i, best_inout, sv, si);
+}
+
+// K4 in ONE workgroup for up to PF_MID_MAX particles on one GPU: the same stages on the same
+// 256-particle blocks, barriers instead of kernel boundaries (one launch instead of eight).
+// tile: the LDS the sequential-order CDF needs when draws were ambiguous; it doubles as the
+// arg-max scratch.
+__global__ __launch_bounds__(WG) void k4_mid(double* cdf, const double* __restrict__ u, int Pg,
+                                             double bound, double* w, float* logw, double* pose,
+                                             int32_t* draw, int32_t* first, int32_t* dup_anc,
+                                             int32_t* slot_anc, int32_t* best,
+                                             unsigned long long* counters, PfResampleScratch sc) {
+    __shared__ double tile[TILE];
+    __shared__ int sd[WG / WAVE], sf[WG / WAVE];
+    __shared__ double sv[WG / WAVE];
+    const int tid = threadIdx.x, grp = tid >> 8, lt = tid & (NB - 1);
+    const int nb = (Pg + NB - 1) / NB;
+    for (int i = tid; i < Pg; i += WG) d_search(i, cdf, u, Pg, bound, draw, counters);
+    __syncthreads();
+    if (bound > 0.0 && ld_agent(&counters[1]) != 0) {       // workgroup-uniform
+        seq_cdf(w, Pg, cdf, tile);
+        __syncthreads();
+    }
+    for (int i = tid; i < Pg; i += WG) d_first(i, cdf, u, draw, Pg, first, counters);
+    __syncthreads();
+    for (int vb0 = 0; vb0 < nb; vb0 += WG / NB)
+        d4_count(vb0 + grp, lt, sd + 4 * grp, sf + 4 * grp, draw, Pg, first, sc.bcnt);
+    __syncthreads();
+    d4_scan(nb, sc.bcnt, sc.boff2, sc.ndup, sd, sf);
+    __syncthreads();
+    for (int vb0 = 0; vb0 < nb; vb0 += WG / NB)
+        d4_scatter(vb0 + grp, lt, sd + 4 * grp, sf + 4 * grp, draw, Pg, first, sc.boff2, dup_anc, slot_anc);
+    __syncthreads();
+    for (int vb0 = 0; vb0 < nb; vb0 += WG / NB)
+        d4_apply<true>(vb0 + grp, lt, sv + 4 * grp, sd + 4 * grp, slot_anc, dup_anc, Pg, w, logw, pose,
+                       sc.bbest_v, sc.bbest_i);
+    __syncthreads();
+    d4_argmax(nb, sc.bbest_v, sc.bbest_i, best, tile, (int*)(tile + WG));
 }
 
 __global__ __launch_bounds__(NB) void k_apply_pose(const int32_t* __restrict__ slot_anc, int P,
@@ -518,6 +658,15 @@ __global__ __launch_bounds__(NB) void k_apply_maps(const int32_t* __restrict__ s
 // launchers
 // ------------------------------------------------------------------------------------------
 static inline int nblocks(int n) { return (n + NB - 1) / NB; }
+// SLAM_PF_MID=1: K3 and K4 as ONE workgroup each (k3_mid, k4_mid) instead of the multi-kernel
+// chains. Off by default: one CU cannot hide the latency of 10k binary searches, measured 67 us
+// (K3) and 172 us (K4) against 18 and 29 us for the chains at 10k particles. Kept because the
+// two forms are the same arithmetic on the same 256-particle blocks and a test compares them
+// bit for bit, which pins the fixed-shape claim the multi-GPU path relies on.
+static inline bool mid_ok(int Pg) {
+    const char* e = getenv("SLAM_PF_MID");
+    return Pg <= PF_MID_MAX && e && atoi(e) != 0;
+}
 
 hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
                        double* cdf, double* scratch, bool exact, int32_t* first,
@@ -528,6 +677,11 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
         return hipGetLastError();
     }
     const int nb = nblocks(Pg);
+    if (mid_ok(Pg)) {
+        hipLaunchKernelGGL(k3_mid, dim3(1), dim3(WG), 0, st, scores, Pg, w, scratch, logw, cdf, first,
+                           counters, sc);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k3_min, dim3(1), dim3(WG), 0, st, scores, Pg, sc.prm);
     hipLaunchKernelGGL(k3_raw, dim3(nb), dim3(NB), 0, st, scores, Pg, w, scratch, sc.prm, sc.bsum,
                        sc.bmax, sc.bse);
@@ -546,6 +700,11 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
                         unsigned long long* counters, PfResampleScratch sc) {
     const int nb = nblocks(Pg);
     // counters[0..2] and first[] were initialised by the weight kernels of this step
+    if (mid_ok(Pg) && P == Pg && !pose_gathered && !(maps && map_stride)) {
+        hipLaunchKernelGGL(k4_mid, dim3(1), dim3(WG), 0, st, (double*)cdf, u, Pg, bound, w, logw, pose,
+                           draw, first, dup_anc, slot_anc, best, counters, sc);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, bound, draw, counters);
     if (bound > 0.0)
         // settle draws that sit within the parallel CDF's rounding error of a boundary on the

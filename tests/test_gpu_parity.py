@@ -166,10 +166,12 @@ def test_shared_grid_step_exact_order(P, M, dims, order):
         h.close()
 
 
-def test_shared_grid_fast_order_large():
+@pytest.mark.parametrize("P", [9000, 20000])
+def test_shared_grid_fast_order_large(P):
     """FAST order at a size where the sequential chain would dominate: scores and resampled
-    indices bit-exact, weights within fp64 rounding, log-weights within 1e-5 relative."""
-    P, M, dims = 20000, 2048, (128, 128, 128)
+    indices bit-exact, weights within fp64 rounding, log-weights within 1e-5 relative.
+    """
+    M, dims = 2048, (128, 128, 128)
     sc = synth.scene(dims, P, M, seed=7)
     w0 = np.full(P, 1.0 / P)
     u = capi.draw_uniform(99, P)
@@ -189,8 +191,47 @@ def test_shared_grid_fast_order_large():
         assert np.allclose(glw, logw, rtol=1e-5, atol=1e-6)
         slots, gbest, gnohit, amb = h.resample(u)
         assert np.array_equal(slots, sa) and gbest == best and gnohit == nohit
+        gw2, _ = h.get_weights()
+        assert np.allclose(gw2, w_after, rtol=1e-12, atol=0)
+        px, py, pz, pyaw = h.get_poses()
+        assert np.array_equal(px, sc["x"][sa]) and np.array_equal(pyaw, sc["yaw"][sa])
     finally:
         h.close()
+
+
+def test_fast_order_one_workgroup_equals_kernel_chain(monkeypatch):
+    """The single-workgroup K3/K4 (SLAM_PF_MID=1, a development form) and the multi-kernel chains are the same
+    arithmetic on the same 256-particle blocks: every output bit-identical, also when draws sit
+    on CDF boundaries (the re-search path)."""
+    P, M, dims = 7001, 256, (64, 64, 64)
+    sc = synth.scene(dims, P, M, seed=5)
+    rng = np.random.default_rng(5)
+    w0 = rng.random(P) + 1e-3; w0 /= w0.sum()
+    out = []
+    for mid in ("1", "0"):
+        monkeypatch.setenv("SLAM_PF_MID", mid)
+        h = capi.Handle(_shared_cfg(P, dims, order_mode=capi.PF_ORDER_FAST))
+        try:
+            h.write_map(0, sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+            h.set_weights(w0); h.set_beams(*sc["beams"]); h.measure(0); h.weights()
+            gw, glw = h.get_weights()
+            # thresholds on and next to boundaries of the CDF the device will build
+            cdf = np.cumsum(gw)
+            u = capi.draw_uniform(77, P)
+            u[:200] = cdf[100:300]
+            u[200:400] = np.nextafter(cdf[300:500], 1.0)
+            u[400] = 0.0; u[401] = 1.0; u[402] = np.nextafter(1.0, 0.0)
+            slots, gbest, gnohit, amb = h.resample(u)
+            gw2, glw2 = h.get_weights()
+            out.append((gw, glw, slots, gbest, gnohit, amb, gw2, glw2, h.get_poses()))
+        finally:
+            h.close()
+    a, b = out
+    assert a[5] > 0                                           # the re-search path did run
+    for x, y in zip(a[:8], b[:8]):
+        assert np.array_equal(x, y)
+    for x, y in zip(a[8], b[8]):
+        assert np.array_equal(x, y)
 
 
 def test_systematic_thresholds_same_kernel():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development aid: K1 time at the C2 size for several particle-order keys
-(SLAM_PF_ORDER=qa,qx,qy,mode; see order_key in pf_kernels.hip)."""
+(SLAM_PF_ORDER=qa,qx,qy,mode,bits; see order_key in pf_kernels.hip)."""
 import os
 import sys
 
@@ -20,11 +20,10 @@ cfg = capi.default_config(n_particles=P, map_mode=capi.PF_MAP_SHARED, grid_x=G, 
 h = capi.Handle(cfg)
 h.write_map(0, sc["grid"]); h.set_beams(*sc["beams"])
 ref = None
-keys = sys.argv[4:] or ["500,2,4,0", "200,2,2,1", "100,1,1,1", "150,1.5,1.5,1", "300,3,3,1", "400,2,2,1",
-                        "200,1,1,1", "300,1.5,1.5,1", "600,2,2,2", "1000,2,2,2", "300,2,2,2"]
+keys = sys.argv[4:] or ["500,2,4,0,5", "300,3,3,1,5", "300,3,3,1,4", "200,2,2,1,4", "400,4,4,1,4", "150,3,3,1,4",
+                        "300,2,2,1,4", "200,3,3,1,4"]
 for key in keys:
-    os.environ["SLAM_PF_ORDER"] = key.split("@")[0]
-    os.environ["SLAM_PF_K1_DBG"] = key.split("@")[1] if "@" in key else "0"
+    os.environ["SLAM_PF_ORDER"] = key
     h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
     for _ in range(3):
         h.measure(0)

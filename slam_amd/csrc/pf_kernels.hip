@@ -207,13 +207,18 @@ __global__ __launch_bounds__(256) void k_measure_fast(
 // flat-only bounds test S3P:882 lets indices alias into the neighbouring row), re-does those
 // beams with the reference fp64 sequence, and turns the flat index back into the cell it names.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c) {   // a*b + c, a, b < 2^24
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ unsigned swz_addr(unsigned X, unsigned Y, unsigned Z, unsigned gy8,
                                              unsigned kz) {
     // ((Z>>3)*gx*gy + X*gy + Y)*8 + (Z&7) = (Z>>3)*(gx*gy*8 - 8) + X*gy*8 + (Y*8 + Z)
-    const unsigned t = __umul24(X, gy8) + ((Y << 3) + Z);
-    return __umul24(Z >> 3, kz) + t;
+    return mad_u24(Z >> 3, kz, mad_u24(X, gy8, (Y << 3) + Z));
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int cvt_floor_i32(float x) {       // (int)floorf(x) in one instruction
     int r;
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
@@ -236,6 +241,7 @@ __global__ __launch_bounds__(256) void k_measure_swz(
     const double ms = -s;
     const float cf = (float)c, sf = (float)s, msf = -sf;
     const float txh = (float)(tx + 0.5), tyh = (float)(ty + 0.5);
+    const v2f rotA = {cf, sf}, rotB = {msf, cf}, trh = {txh, tyh};
     const int zp = (int)round(tz);                               // exact: |tz| < 2^24
     const double tmax = fmax(fmax(fabs(tx), fabs(ty)), fabs(tz));
     float E = (float)(2.5e-7 * (lmax + tmax + 1.0) + 1.0e-7);
@@ -251,6 +257,9 @@ __global__ __launch_bounds__(256) void k_measure_swz(
     // The issue arbiter favours the oldest wave, which staggers the finish times of a launch
     // that is one residency deep and leaves the CUs half empty at the end. Waves in the first
     // half of their beams therefore run at a higher priority than waves in the second half.
+    // (Tried instead, and slower: a per-slot work queue that hands beam batches to whichever
+    // wave is free, 44 us against 39 us, the same-address atomics cost more than the tail;
+    // an XCD-aware chunk map so each L2 sees an eighth of the beams, no measurable change.)
     const int j_half = M / 2;
     __builtin_amdgcn_s_setprio(2);
     for (int j = blockIdx.y * PF_BEAM_GROUP; j < M; j += gridDim.y * PF_BEAM_GROUP) {
@@ -261,14 +270,19 @@ __global__ __launch_bounds__(256) void k_measure_swz(
         bool okall = true;
 #pragma unroll
         for (int k = 0; k < PF_BEAM_GROUP; ++k) {
-            const float xh = fmaf(cf, g.lx[k], fmaf(msf, g.ly[k], txh));
-            const float yh = fmaf(sf, g.lx[k], fmaf(cf, g.ly[k], tyh));
-            X[k] = cvt_floor_i32(xh); Y[k] = cvt_floor_i32(yh); Z[k] = g.lz[k] + zp;
-            const float fx = __builtin_amdgcn_fractf(xh), fy = __builtin_amdgcn_fractf(yh);
+            // (xh, yh) as one packed pair: two v_pk_fma_f32, the beam's lx / ly broadcast from SGPRs
+            const v2f lxx = {g.lx[k], g.lx[k]}, lyy = {g.ly[k], g.ly[k]};
+            const v2f h = __builtin_elementwise_fma(rotA, lxx, __builtin_elementwise_fma(rotB, lyy, trh));
+            X[k] = cvt_floor_i32(h.x); Y[k] = cvt_floor_i32(h.y); Z[k] = g.lz[k] + zp;
+            const float fx = __builtin_amdgcn_fractf(h.x), fy = __builtin_amdgcn_fractf(h.y);
             gmin = __builtin_fminf(gmin, __builtin_fminf(fx, fy));
             gmax = __builtin_fmaxf(gmax, __builtin_fmaxf(fx, fy));
-            okall &= ((unsigned)X[k] < gxu) & ((unsigned)Y[k] < gyu) & ((unsigned)Z[k] < gzu);
         }
+        // axis ranges once per group: as unsigned, a negative coordinate is a huge one
+        const unsigned xm = max(max((unsigned)X[0], (unsigned)X[1]), max((unsigned)X[2], (unsigned)X[3]));
+        const unsigned ym = max(max((unsigned)Y[0], (unsigned)Y[1]), max((unsigned)Y[2], (unsigned)Y[3]));
+        const unsigned zm = max(max((unsigned)Z[0], (unsigned)Z[1]), max((unsigned)Z[2], (unsigned)Z[3]));
+        okall = (xm < gxu) & (ym < gyu) & (zm < gzu);
         const bool fine = (gmin >= E) & (gmax <= hi) & okall;
         if (__builtin_expect(__all(fine), 1)) {
             unsigned v[PF_BEAM_GROUP];

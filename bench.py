@@ -77,6 +77,19 @@ def cpu_baseline(sc, dims, P, M, seconds):
                       f"{dims[0]}^3 grid) in {el:.1f} s, 1 thread, gcc -O2"}
 
 
+def k1_traffic(P, M, grid):
+    """HBM-side bytes per K1 launch from the committed PMC passes (profiles/r1_k1_traffic.json,
+    made by tools/pmc_k1.sh), or None when this run is not the workload they were taken on."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_k1_traffic.json")) as f:
+            t = json.load(f)
+    except OSError:
+        return None
+    if (P, M, grid) != (10000, 4096, 256):
+        return None
+    return t["traffic_bytes_per_launch"]
+
+
 def main():
     a = parse()
     import torch
@@ -201,9 +214,9 @@ def main():
                        "particles_per_gpu": P, "particles_total": Pg, "beams": M,
                        "grid": list(dims), "order": "fast" if Pg > 2048 else "exact",
                        "ambiguous_draws": int(amb_total), "nohit_draws": int(nohit_total)},
-            "roofline": {"bound": "hbm", "kernel": "k_measure_fast", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_measure_swz", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "algorithmic_bytes_per_launch": k1_bytes,
+                         "traffic": k1_traffic(P, M, a.grid), "algorithmic_bytes_per_launch": k1_bytes,
                          "avg_launch_us": k1_avg_s * 1e6, "launches": int(k1_n),
                          "k1_evals_per_s": P * M / k1_avg_s if k1_avg_s > 0 else 0.0},
             "kernel_us": {"measure": k1_ms / max(k1_n, 1) * 1e3, "weights": k3_ms / max(k3_n, 1) * 1e3,

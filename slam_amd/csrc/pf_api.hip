@@ -562,11 +562,11 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     return PF_OK;
 }
 
-// K1 lane order: Morton key over (yaw, x/res, y/res) in cells of 1/300 rad and 1/3 voxel; 4 bits
+// K1 lane order: Morton key over (yaw, x/res, y/res) in cells of 1/200 rad and 1/3 voxel; 4 bits
 // per axis sort 64-lane waves finely enough up to 64k particles per handle, 5 bits beyond.
 // SLAM_PF_ORDER=qa,qx,qy,mode,bits overrides (development knob).
 static PfOrderParams order_params(const pf_handle* h) {
-    PfOrderParams op{300.0, 3.0, 3.0, 1, h->P <= 65536 ? 4 : 5};
+    PfOrderParams op{200.0, 3.0, 3.0, 1, h->P <= 65536 ? 4 : 5};
     if (const char* e = getenv("SLAM_PF_ORDER")) {
         double a, x, y; int m, b;
         if (sscanf(e, "%lf,%lf,%lf,%d,%d", &a, &x, &y, &m, &b) == 5 && (b == 4 || b == 5))

@@ -30,8 +30,10 @@ class ShardedBackend:
         self.Pg = handle.Pg
         if self.P * self.world != self.Pg:
             raise ValueError("shards must be equal: n_particles * world != n_particles_global")
-        s = handle.scores_tensor()
-        p = handle.poses_tensor()
+        # zero-copy views of the handle's device buffers (fixed addresses): made once, the
+        # __cuda_array_interface__ import costs tens of microseconds per call
+        s = self._scores = handle.scores_tensor()
+        p = self._poses = handle.poses_tensor()
         # rank blocks concatenated along dim 0: [world*P, 2] and [world*9, P]
         self._scores_all = torch.empty((self.world * s.shape[0], s.shape[1]), dtype=s.dtype,
                                        device=s.device)
@@ -64,15 +66,13 @@ class ShardedBackend:
 
     def weights(self):
         self._before_collective()
-        s = self.h.scores_tensor()
-        self.dist.all_gather_into_tensor(self._scores_all, s, group=self.group)     # C1
+        self.dist.all_gather_into_tensor(self._scores_all, self._scores, group=self.group)   # C1
         self._after_collective(self._scores_all)
         self.h.weights(self._scores_all.data_ptr())
 
     def resample(self, u=None, want_slots=True):
         self._before_collective()
-        p = self.h.poses_tensor()
-        self.dist.all_gather_into_tensor(self._poses_all, p, group=self.group)      # C2
+        self.dist.all_gather_into_tensor(self._poses_all, self._poses, group=self.group)     # C2
         self._after_collective(self._poses_all)
         return self.h.resample(u, self._poses_all.data_ptr(), want_slots)
 

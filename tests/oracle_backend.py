@@ -96,11 +96,11 @@ class OracleHandle:
                 a = sa[self.offset + i]
                 if a != self.offset + i:
                     new[:, i] = allp[a // self.P, :, a % self.P]
-            self.pose = new
+            self.pose[...] = new      # in place: the buffer address is fixed, like the device one
         else:
             rec = np.ascontiguousarray(self.pose.T)
             O.permute(sa, rec)
-            self.pose = np.ascontiguousarray(rec.T)
+            self.pose[...] = rec.T
             if self.per_particle:
                 O.permute(sa, self.maps)
         lw = self.logw.copy()

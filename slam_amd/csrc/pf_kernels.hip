@@ -543,7 +543,8 @@ hipError_t pfk_voxel_indices(hipStream_t st, const double* pose, int P, int i,
 // reproduces the reference's sequential loop exactly. Hits complete (kernel boundary) before
 // the ray march starts, as in S3P:632-661 then S3P:668-704.
 // ------------------------------------------------------------------------------------------
-__device__ inline void cell_touch(void* grid, long long f, int inc, int clampv, bool hit,
+// Returns false when the cell was already at its clamp for this touch (nothing written).
+__device__ inline bool cell_touch(void* grid, long long f, int inc, int clampv, bool hit,
                                   bool is_signed) {
     unsigned* wp = (unsigned*)grid + (f >> 2);
     const unsigned shft = (unsigned)(f & 3) * 8u;
@@ -553,10 +554,10 @@ __device__ inline void cell_touch(void* grid, long long f, int inc, int clampv, 
         const int v = is_signed ? (int)(int8_t)byte : (int)byte;
         int nv = v + inc;
         if (hit ? nv > clampv : nv < clampv) nv = clampv;
-        if (nv == v) return;
+        if (nv == v) return false;
         const unsigned nw = (old & ~(0xffu << shft)) | (((unsigned)nv & 0xffu) << shft);
         const unsigned seen = atomicCAS(wp, old, nw);
-        if (seen == old) return;
+        if (seen == old) return true;
         old = seen;
     }
 }
@@ -598,8 +599,10 @@ __global__ __launch_bounds__(256) void k_update_hits(void* grid, const double* _
     if (nrm > up.max_range) return;                              // S3P:637 (NaN falls through)
     const long long f = flat_of(wx * up.conv, wy * up.conv, wz * up.conv, up);
     if (f < 0) return;
-    cell_touch(grid, f, up.hit_inc, up.hit_clamp, true, up.is_signed != 0);
-    shadow_touch(up, f, up.hit_inc, up.hit_clamp, true);
+    // a touch that found the cell saturated in one copy finds it saturated in the other: the two
+    // copies receive the same touches, and within a phase a saturated cell stays saturated
+    if (cell_touch(grid, f, up.hit_inc, up.hit_clamp, true, up.is_signed != 0))
+        shadow_touch(up, f, up.hit_inc, up.hit_clamp, true);
 }
 
 // One wave per ray; lane l takes steps j = 1+l, 65+l, ... (S3P:685: j = 1 .. n_it-1).
@@ -622,8 +625,8 @@ __global__ __launch_bounds__(256) void k_update_rays(void* grid, const double* _
         const long long f = flat_of((up.pos[0] + sx * jd) * up.conv, (up.pos[1] + sy * jd) * up.conv,
                                     (up.pos[2] + sz * jd) * up.conv, up);   // S3P:687-690
         if (f >= 0) {
-            cell_touch(grid, f, up.miss_inc, up.miss_clamp, false, up.is_signed != 0);
-            shadow_touch(up, f, up.miss_inc, up.miss_clamp, false);
+            if (cell_touch(grid, f, up.miss_inc, up.miss_clamp, false, up.is_signed != 0))
+                shadow_touch(up, f, up.miss_inc, up.miss_clamp, false);
         }
     }
 }

@@ -251,15 +251,16 @@ def test_systematic_thresholds_same_kernel():
         h.close()
 
 
-def test_edge_cases_bounds_aliasing_and_empty():
-    dims = (32, 24, 16)
+@pytest.mark.parametrize("dims", [(32, 24, 16), (31, 23, 19)])
+def test_edge_cases_bounds_aliasing_and_empty(dims):
+    """dims not multiples of 8 exercise the padding of K1's gather layout (8-cell z octets)."""
     P = 130
     rng = np.random.default_rng(5)
     grid = rng.integers(0, 101, dims).astype(np.uint8)
     # poses near and beyond the grid faces: out-of-bounds flats and the flat-only aliasing of
     # S3P:882 (y = -1 or z = gz alias into a neighbouring row) must match the oracle
-    x = rng.uniform(-0.3, 32 * 0.05 + 0.3, P); y = rng.uniform(-0.3, 24 * 0.05 + 0.3, P)
-    z = rng.uniform(-0.2, 16 * 0.05 + 0.2, P); yaw = rng.uniform(-3.2, 3.2, P)
+    x = rng.uniform(-0.3, dims[0] * 0.05 + 0.3, P); y = rng.uniform(-0.3, dims[1] * 0.05 + 0.3, P)
+    z = rng.uniform(-0.2, dims[2] * 0.05 + 0.2, P); yaw = rng.uniform(-3.2, 3.2, P)
     M = 900
     bx = rng.integers(-20, 21, M).astype(np.int32); by = rng.integers(-20, 21, M).astype(np.int32)
     bz = rng.integers(-10, 11, M).astype(np.int32)
@@ -362,6 +363,44 @@ def test_update_map_shared_uint8_matches_oracle():
         h.set_scan(pts, np.arange(len(pts), dtype=np.int32))      # north-star: every beam is cast
         h.update_map(capi.PF_GRID_SHARED, capi.UpdateParams(*prm, 3.0), pos, zyx)
         assert np.array_equal(h.read_map(0).reshape(dims), want)
+    finally:
+        h.close()
+
+
+def test_measure_sees_map_updates_in_both_layouts():
+    """K1 reads a gather-layout copy of the shared grid; K5 keeps it in step with the
+    reference-order copy. Measure -> update -> measure -> upload -> measure against the oracle
+    on the same sequence of grids (dims not multiples of 8)."""
+    dims = (90, 70, 44)
+    P, M = 700, 600
+    sc = synth.scene(dims, P, M, seed=21)
+    grid = sc["grid"].copy()
+    og = O.ref_grid(*dims)
+    ucfg = O.UpdateCfg(dims[0], dims[1], dims[2], 0.05, 0, 10, 100, -3, 0, 3.0)
+    tp = sc["true_pose"]
+    pos = tp[:3].copy(); zyx = np.array([tp[3], 0.02, -0.01])
+    h = capi.Handle(_shared_cfg(P, dims))
+    try:
+        h.write_map(0, grid); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+        h.set_beams(*sc["beams"]); h.set_scan(sc["points"], sc["ray_idx"])
+        for rnd in range(3):
+            h.measure(0)
+            s, c = O.measure(og, sc["x"], sc["y"], sc["z"], sc["yaw"], grid.reshape(-1), 0, *sc["beams"], 0)
+            gs, gc = h.get_scores()
+            assert np.array_equal(gs, s) and np.array_equal(gc, c), rnd
+            h.update_map(capi.PF_GRID_SHARED, capi.UpdateParams(10, 100, -3, 0, 3.0), pos, zyx)
+            O.update_map(ucfg, grid, pos, zyx, sc["points"], sc["ray_idx"])
+            assert np.array_equal(h.read_map(0).reshape(dims), grid)
+            pos = pos + np.array([0.07, -0.04, 0.01])
+        # a map written from outside replaces both copies
+        grid = np.random.default_rng(3).integers(0, 101, dims).astype(np.uint8)
+        h.write_map(0, grid); h.measure(0)
+        s, c = O.measure(og, sc["x"], sc["y"], sc["z"], sc["yaw"], grid.reshape(-1), 0, *sc["beams"], 0)
+        gs, gc = h.get_scores()
+        assert np.array_equal(gs, s) and np.array_equal(gc, c)
+        h.fill_maps(37); h.measure(0)
+        gs, gc = h.get_scores()
+        assert np.array_equal(gs, 37 * gc)
     finally:
         h.close()
 

@@ -9,7 +9,8 @@ uint8 grid. N>1: the same per GPU (weak scaling): particles sharded in equal blo
 replicated, one RCCL all-gather of the scores and one of the pose blocks per step.
 
 A step = one pass of the hot path on inputs resident in HBM, in the reference's order:
-measure (K1) -> predict -> weights (K3) -> resample (K4) -> update_map (K5, every beam cast).
+measure (K1) -> update_map (K5, every beam cast) -> predict -> weights (K3) ->
+resample (K4).
 The caller-side work (the motion model with its host-libm trig, the beam list, the scan, the
 thresholds) happens before the timed region, as the contract's "inputs already resident"
 asks: the predicted pose blocks of the steps are computed by pf_predict beforehand, kept in
@@ -41,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-update", action="store_true", help="leave K5 out of the step")
+    ap.add_argument("--time-all-kernels", action="store_true",
+                    help="HIP events around K3/K4/K5 too (kernel_us); costs host time in the step")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal: use the multi-GPU code path (RCCL all-gathers) even at N=1")
     return ap.parse_args()
@@ -160,13 +163,13 @@ def main():
 
     def step(first=False):
         be.measure(0)
+        if not a.no_update:
+            # the grid update only has to follow this step's measure and precede the next one
+            h.update_map(capi.PF_GRID_SHARED, upd, pos, zyx)
         h.predict_device(block_ptrs[step_no[0] % NBLK])
         step_no[0] += 1
         be.weights()
-        r = be.resample(u if first else None, want_slots=False)
-        if not a.no_update:
-            h.update_map(capi.PF_GRID_SHARED, upd, pos, zyx)
-        return r
+        return be.resample(u if first else None, want_slots=False)
 
     def fence():
         h.synchronize()
@@ -177,7 +180,8 @@ def main():
     step(first=True)                                 # makes the thresholds resident
     for _ in range(a.warmup):
         step()
-    h.profile(True)
+    # K1 is timed live with HIP events on its stream (roofline); the other classes only on request
+    h.profile(True, None if a.time_all_kernels else [capi.PF_K_MEASURE])
     fence()
     t0 = time.perf_counter()
     amb_total = nohit_total = 0

@@ -187,7 +187,9 @@ void* pf_stream(pf_handle* h);                           /* the hipStream_t the 
  * handle's own stream. The caller keeps ownership of its stream. */
 int pf_set_stream(pf_handle* h, void* hip_stream);
 int pf_synchronize(pf_handle* h);
-/* HIP-event timing of the kernels, per class; off by default. */
+/* HIP-event timing of the kernels, per class; off by default. enable: 0 off, 1 every class,
+ * otherwise 2 * (bit mask of PF_K_* classes), e.g. 2 * (1 << PF_K_MEASURE) times K1 only (two
+ * event records per step instead of eight). */
 int pf_profile(pf_handle* h, int enable);
 int pf_kernel_time(pf_handle* h, int kernel_id, double* total_ms, int64_t* launches);
 

@@ -273,8 +273,12 @@ class Handle:
     def synchronize(self):
         self._ck(lib().pf_synchronize(self._h), "pf_synchronize")
 
-    def profile(self, on):
-        self._ck(lib().pf_profile(self._h, int(on)), "pf_profile")
+    def profile(self, on, only=None):
+        """on: bool; only: iterable of PF_K_* classes to time (default every class)."""
+        v = int(bool(on))
+        if on and only is not None:
+            v = 2 * sum(1 << int(k) for k in only)
+        self._ck(lib().pf_profile(self._h, v), "pf_profile")
 
     def kernel_time(self, kid):
         ms = C.c_double(0); n = C.c_int64(0)

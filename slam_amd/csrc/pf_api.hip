@@ -58,7 +58,8 @@ struct pf_handle {
     int32_t* free_slot = nullptr;      // [Pg]
     int32_t* slot_anc = nullptr;       // [Pg]
     int32_t* best = nullptr;           // inside `counters`' allocation: one D2H copy returns all
-    unsigned long long* h_result = nullptr;    // pinned host mirror of counters[3] + best
+    unsigned long long* h_result = nullptr;    // pinned host memory K4's last kernel writes {counters[3], best} to
+    unsigned long long* d_result = nullptr;    // the same memory as the device sees it
     unsigned long long* counters = nullptr;   // [3]
     PfResampleScratch rs{};            // block-level scratch of K3/K4
     void* rs_mem = nullptr;
@@ -375,7 +376,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->slot_anc, Pg));
     CREATE_TRY(dalloc(&h->counters, 4));            // [0..2] counters, [3] holds `best`
     h->best = (int32_t*)(h->counters + 3);
-    CREATE_TRY(hipHostMalloc((void**)&h->h_result, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_result, 4 * sizeof(unsigned long long), hipHostMallocMapped));
+    CREATE_TRY(hipHostGetDevicePointer((void**)&h->d_result, h->h_result, 0));
     {
         // one allocation, carved: 6 double arrays of nb (+8 for prm), 2 int2 arrays, 1 int array, ndup
         const size_t nb = (Pg + 255) / 256;
@@ -725,11 +727,9 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
             return pfk_resample(h->stream, h->cdf, h->u, h->Pg, h->P, h->offset, bound, h->w, h->logw,
                                 h->pose, (const double*)poses_global_dev, h->slab ? h->maps : nullptr,
                                 h->slab, (unsigned long long)h->elements, h->draw, h->first, h->dup_anc,
-                                h->free_slot, h->slot_anc, h->best, h->counters, h->rs);
+                                h->free_slot, h->slot_anc, h->best, h->counters, h->rs, h->d_result);
         }));
     }
-    HIP_TRY(h, hipMemcpyAsync(h->h_result, h->counters, 4 * sizeof(unsigned long long),
-                              hipMemcpyDeviceToHost, h->stream));
     if (slot_anc_out)
         HIP_TRY(h, hipMemcpyAsync(slot_anc_out, h->slot_anc, sizeof(int32_t) * (size_t)h->Pg,
                                   hipMemcpyDeviceToHost, h->stream));

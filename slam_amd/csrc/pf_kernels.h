@@ -99,13 +99,15 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
 // K4: S3P:757-821, the whole chain on the stream, no host round trip: search (+ re-search of
 // ambiguous draws on the sequential-order CDF when bound > 0), slot assignment, permutation of
 // weights / pose rows / map slabs, arg-max. counters: unsigned long long [3] = {no-hit draws,
-// ambiguous draws, no-hit draws after the re-search}.
+// ambiguous draws, no-hit draws after the re-search}. host_out: device-visible pinned host
+// memory, unsigned long long [4], receives {counters[0..2], best} from the last kernel.
 hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int Pg, int P,
                         int offset, double bound, double* w, float* logw, double* pose,
                         const double* pose_gathered, uint8_t* maps, unsigned long long map_stride,
                         unsigned long long map_bytes, int32_t* draw, int32_t* first,
                         int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
-                        unsigned long long* counters, PfResampleScratch sc);
+                        unsigned long long* counters, PfResampleScratch sc,
+                        unsigned long long* host_out);
 
 // K5: S3P:628-704. rot9: row-major ZYX matrix from the host libm. wpts: double [M][3] scratch.
 struct PfUpdateParams {

@@ -552,8 +552,13 @@ __global__ __launch_bounds__(NB) void k4_apply(int32_t* __restrict__ slot_anc,
     __shared__ int si[NB / WAVE];
     d4_apply<POSE>(blockIdx.x, threadIdx.x, sv, si, slot_anc, dup_anc, Pg, w, logw, pose, bbest_v, bbest_i);
 }
+// host_out (may be null): pinned host memory the last stage of K4 writes the step's results to
+// ({no-hit draws, ambiguous draws, no-hit draws after the re-search, best}); the stream
+// synchronisation the caller does anyway makes them visible, no copy is enqueued.
 __device__ inline void d4_argmax(int nb, const double* bbest_v, const int32_t* bbest_i,
-                                 int32_t* best_inout, double* sv, int* si) {
+                                 int32_t* best_inout, double* sv, int* si,
+                                 const unsigned long long* counters = nullptr,
+                                 unsigned long long* host_out = nullptr) {
     const int tid = threadIdx.x;
     double v = 0.0; int idx = -1;
     for (int k = tid; k < nb; k += WG) {
@@ -572,14 +577,23 @@ __device__ inline void d4_argmax(int nb, const double* bbest_v, const int32_t* b
         }
         __syncthreads();
     }
-    if (tid == 0 && si[0] >= 0) *best_inout = si[0];        // otherwise the previous index stays
+    if (tid == 0) {
+        int b = *best_inout;
+        if (si[0] >= 0) *best_inout = b = si[0];            // otherwise the previous index stays
+        if (host_out) {
+            host_out[0] = ld_agent(&counters[0]); host_out[1] = ld_agent(&counters[1]);
+            host_out[2] = ld_agent(&counters[2]); host_out[3] = (unsigned long long)(unsigned)b;
+        }
+    }
 }
 __global__ __launch_bounds__(WG) void k4_argmax(int nb, const double* __restrict__ bbest_v,
                                                 const int32_t* __restrict__ bbest_i,
-                                                int32_t* best_inout) {
+                                                int32_t* best_inout,
+                                                const unsigned long long* counters,
+                                                unsigned long long* host_out) {
     __shared__ double sv[WG];
     __shared__ int si[WG];
-    d4_argmax(nb, bbest_v, bbest_i, best_inout, sv, si);
+    d4_argmax(nb, bbest_v, bbest_i, best_inout, sv, si, counters, host_out);
 }
 
 // K4 in ONE workgroup for up to PF_MID_MAX particles on one GPU: the same stages on the same
@@ -590,7 +604,8 @@ __global__ __launch_bounds__(WG) void k4_mid(double* cdf, const double* __restri
                                              double bound, double* w, float* logw, double* pose,
                                              int32_t* draw, int32_t* first, int32_t* dup_anc,
                                              int32_t* slot_anc, int32_t* best,
-                                             unsigned long long* counters, PfResampleScratch sc) {
+                                             unsigned long long* counters, PfResampleScratch sc,
+                                             unsigned long long* host_out) {
     __shared__ double tile[TILE];
     __shared__ int sd[WG / WAVE], sf[WG / WAVE];
     __shared__ double sv[WG / WAVE];
@@ -616,7 +631,7 @@ __global__ __launch_bounds__(WG) void k4_mid(double* cdf, const double* __restri
         d4_apply<true>(vb0 + grp, lt, sv + 4 * grp, sd + 4 * grp, slot_anc, dup_anc, Pg, w, logw, pose,
                        sc.bbest_v, sc.bbest_i);
     __syncthreads();
-    d4_argmax(nb, sc.bbest_v, sc.bbest_i, best, tile, (int*)(tile + WG));
+    d4_argmax(nb, sc.bbest_v, sc.bbest_i, best, tile, (int*)(tile + WG), counters, host_out);
 }
 
 __global__ __launch_bounds__(NB) void k_apply_pose(const int32_t* __restrict__ slot_anc, int P,
@@ -697,12 +712,13 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
                         const double* pose_gathered, uint8_t* maps, unsigned long long map_stride,
                         unsigned long long map_bytes, int32_t* draw, int32_t* first,
                         int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
-                        unsigned long long* counters, PfResampleScratch sc) {
+                        unsigned long long* counters, PfResampleScratch sc,
+                        unsigned long long* host_out) {
     const int nb = nblocks(Pg);
     // counters[0..2] and first[] were initialised by the weight kernels of this step
     if (mid_ok(Pg) && P == Pg && !pose_gathered && !(maps && map_stride)) {
         hipLaunchKernelGGL(k4_mid, dim3(1), dim3(WG), 0, st, (double*)cdf, u, Pg, bound, w, logw, pose,
-                           draw, first, dup_anc, slot_anc, best, counters, sc);
+                           draw, first, dup_anc, slot_anc, best, counters, sc, host_out);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, bound, draw, counters);
@@ -732,6 +748,7 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
         hipLaunchKernelGGL(k_apply_maps, dim3(P, gy), dim3(NB), 0, st, slot_anc, P, offset, maps,
                            map_stride, map_bytes);
     }
-    hipLaunchKernelGGL(k4_argmax, dim3(1), dim3(WG), 0, st, nb, sc.bbest_v, sc.bbest_i, best);
+    hipLaunchKernelGGL(k4_argmax, dim3(1), dim3(WG), 0, st, nb, sc.bbest_v, sc.bbest_i, best, counters,
+                       host_out);
     return hipGetLastError();
 }

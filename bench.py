@@ -74,8 +74,37 @@ def cpu_baseline(sc, dims, P, M, seconds):
         el = time.perf_counter() - t0
         if el >= seconds or reps >= 50:
             break
+    # (ii) of SURVEY 8d: the same step with the measure loop split over the host cores this job
+    # may use (particles are independent, S3P:859; ctypes releases the GIL), the rest serial
+    from concurrent.futures import ThreadPoolExecutor
+    cores = max(1, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1))
+    cores = min(cores, 64)
+    cuts = np.linspace(0, P, cores + 1).astype(int)
+    flat = grid.reshape(-1)
+
+    def part(k):
+        lo, hi = cuts[k], cuts[k + 1]
+        return O.measure(g, sc["x"][lo:hi], sc["y"][lo:hi], sc["z"][lo:hi], sc["yaw"][lo:hi], flat, 0,
+                         *sc["beams"], 0)
+
+    reps_mt, t1 = 0, time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        while True:
+            res = list(ex.map(part, range(cores)))
+            s = np.concatenate([r[0] for r in res]); c = np.concatenate([r[1] for r in res])
+            ww = w.copy()
+            O.weights(ww, s, int(c[-1]))
+            O.resample(ww, u, 0)
+            O.update_map(ucfg, grid.reshape(dims), pos, zyx, sc["points"], sc["ray_idx"])
+            reps_mt += 1
+            el_mt = time.perf_counter() - t1
+            if el_mt >= seconds / 2 or reps_mt >= 200:
+                break
     return {"value": reps * P * M / el, "unit": "evals/s", "cores": 1, "kind": "port",
             "measure_only_value": reps * P * M / t_measure,
+            "all_cores": {"value": reps_mt * P * M / el_mt, "unit": "evals/s", "cores": cores,
+                          "sample": f"{reps_mt} whole steps in {el_mt:.1f} s, measure loop split over "
+                                    f"{cores} threads by particle, weights/resample/update serial"},
             "sample": f"{reps} whole steps of the N=1 workload ({P} particles x {M} beams, "
                       f"{dims[0]}^3 grid) in {el:.1f} s, 1 thread, gcc -O2"}
 

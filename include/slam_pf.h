@@ -207,6 +207,13 @@ void pfh_draw_noise(uint32_t seed, int64_t n, float sigma_pos, float sigma_rot, 
 void pfh_draw_uniform(uint32_t seed, int64_t n, double* u);
 /* S3P:941-953: returns the new add_points and updates last[4] when the pose moved > 0.4. */
 int pfh_add_points_policy(const double pose[4], double last[4], double threshold);
+/* The pose hypothesis behind an index pf_scan_vote returns (loop order r, x, y, z of S3P:328-348):
+ * out = {Tx_loc, Ty_loc, Tz_loc, rot_z_loc} as S3P:366-371 would have stored them. Returns 0, or -1
+ * when `index` is outside the lattice (pf_scan_vote's "no vote" -1 included: out = the input pose,
+ * which is what S3P:326-327 initialises the result to). */
+int pfh_vote_hypothesis(int64_t index, const double pos[3], const double zyx[3], double resolution,
+                        int32_t n_yaw, int32_t yaw_k0, int32_t yaw_kstep, int32_t n_t, double length,
+                        double out[4]);
 /* S3P:805-812 on the caller's own per-particle records. */
 void pfh_permute(int64_t n, const int32_t* slot_anc, void* records, size_t width);
 

@@ -25,7 +25,7 @@ SYMBOLS = (
     "pf_poses_device pf_set_scan pf_update_map pf_scan_vote pf_write_local_map pf_read_local_map "
     "pf_reset_local_map pf_stream pf_set_stream pf_synchronize pf_profile pf_kernel_time "
     "pfh_snapshot_beams pfh_predict pfh_draw_noise pfh_draw_uniform pfh_add_points_policy "
-    "pfh_permute").split()
+    "pfh_permute pfh_vote_hypothesis").split()
 
 
 class Config(C.Structure):
@@ -325,6 +325,16 @@ def add_points_policy(pose, last, threshold=0.4):
     pose = _c(pose, np.float64)
     assert last.dtype == np.float64 and last.flags.c_contiguous and len(last) == 4
     return int(lib().pfh_add_points_policy(_p(pose), _p(last), C.c_double(threshold)))
+
+
+def vote_hypothesis(index, pos, zyx, resolution=0.05, n_yaw=5, yaw_k0=-6, yaw_kstep=3, n_t=5,
+                    length=0.25):
+    """(Tx, Ty, Tz, rot_z) of lattice index `index` (S3P:328-348); None for -1 / out of range."""
+    pos = _c(pos, np.float64); zyx = _c(zyx, np.float64)
+    out = np.empty(4, np.float64)
+    rc = lib().pfh_vote_hypothesis(C.c_int64(int(index)), _p(pos), _p(zyx), C.c_double(resolution),
+                                   n_yaw, yaw_k0, yaw_kstep, n_t, C.c_double(length), _p(out))
+    return out if rc == 0 else None
 
 
 def permute(slot_anc, records):

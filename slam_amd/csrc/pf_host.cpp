@@ -70,6 +70,23 @@ int pfh_add_points_policy(const double pose[4], double last[4], double threshold
     return 0;
 }
 
+int pfh_vote_hypothesis(int64_t index, const double pos[3], const double zyx[3], double resolution,
+                        int32_t n_yaw, int32_t yaw_k0, int32_t yaw_kstep, int32_t n_t, double length,
+                        double out[4]) {
+    out[0] = pos[0]; out[1] = pos[1]; out[2] = pos[2]; out[3] = zyx[0];      // S3P:326-327
+    const int64_t per = (int64_t)n_t * n_t * n_t;
+    if (index < 0 || n_yaw < 1 || n_t < 1 || index >= per * n_yaw) return -1;
+    const double pi = 2 * acos(0.0);                                         // S3P:24
+    const int r = (int)(index / per);
+    const int64_t k = index - (int64_t)r * per;
+    const int a = (int)(k / ((int64_t)n_t * n_t)), b = (int)((k / n_t) % n_t), d = (int)(k % n_t);
+    out[0] = pos[0] + a * resolution - (length - resolution) / 2;           // S3P:335
+    out[1] = pos[1] + b * resolution - (length - resolution) / 2;           // S3P:341
+    out[2] = pos[2] + d * resolution - (length - resolution) / 2;           // S3P:348
+    out[3] = zyx[0] + (yaw_k0 + yaw_kstep * r) * pi / 180;                  // S3P:329
+    return 0;
+}
+
 void pfh_permute(int64_t n, const int32_t* slot_anc, void* records, size_t width) {
     char* r = (char*)records;                              // S3P:805-812
     for (int64_t i = 0; i < n; ++i)

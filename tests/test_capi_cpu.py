@@ -87,6 +87,24 @@ def test_host_helpers_match_oracle():
     assert capi.add_points_policy([7.8, 7.6, 1.5, 0.1], last) == 1 and last[0] == 7.8
 
 
+def test_vote_hypothesis_enumeration():
+    """pfh_vote_hypothesis walks the lattice in the loop order of S3P:328-348 (r, x, y, z)."""
+    pos = np.array([5.01, 4.97, 1.52]); zyx = np.array([0.3, 0.01, -0.02])
+    res, length, n_yaw, n_t = 0.05, 0.25, 5, 5
+    k = 0
+    for r in range(n_yaw):
+        rz = zyx[0] + (-6 + 3 * r) * (2 * np.arccos(0.0)) / 180
+        for a in range(n_t):
+            for b in range(n_t):
+                for d in range(n_t):
+                    want = [pos[0] + a * res - (length - res) / 2, pos[1] + b * res - (length - res) / 2,
+                            pos[2] + d * res - (length - res) / 2, rz]
+                    got = capi.vote_hypothesis(k, pos, zyx)
+                    assert np.array_equal(got, np.array(want)), k
+                    k += 1
+    assert capi.vote_hypothesis(-1, pos, zyx) is None and capi.vote_hypothesis(k, pos, zyx) is None
+
+
 def test_resample_oracle_properties():
     """Size-independent properties of the resampler the GPU tests also use."""
     rng = np.random.default_rng(1)

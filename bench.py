@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-update", action="store_true", help="leave K5 out of the step")
     ap.add_argument("--time-all-kernels", action="store_true",
                     help="HIP events around K3/K4/K5 too (kernel_us); costs host time in the step")
+    ap.add_argument("--torch-collectives", action="store_true",
+                    help="sharded runs: all-gathers through torch.distributed instead of the library's own RCCL calls")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal: use the multi-GPU code path (RCCL all-gathers) even at N=1")
     return ap.parse_args()
@@ -168,7 +170,7 @@ def main():
         work_stream = torch.cuda.Stream(device=local_rank)
         torch.cuda.set_stream(work_stream)
         h.set_stream(work_stream.cuda_stream)
-    be = ShardedBackend(h, dist) if sharded else h
+    be = ShardedBackend(h, dist, native=not a.torch_collectives) if sharded else h
     h.write_map(0, sc["grid"])
     h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
     h.set_weights(np.full(Pg, 1.0 / Pg))
@@ -246,6 +248,7 @@ def main():
                                    + ("" if a.no_update else "+update_map(all beams cast)"),
                        "particles_per_gpu": P, "particles_total": Pg, "beams": M,
                        "grid": list(dims), "order": "fast" if Pg > 2048 else "exact",
+                       "collectives": ("rccl in-library" if getattr(be, "native", False) else "torch.distributed nccl") if sharded else "none",
                        "ambiguous_draws": int(amb_total), "nohit_draws": int(nohit_total)},
             "roofline": {"bound": "hbm", "kernel": "k_measure_swz", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,

@@ -182,6 +182,16 @@ int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const dou
 
 /* ---- plumbing ------------------------------------------------------------------------------ */
 void* pf_stream(pf_handle* h);                           /* the hipStream_t the handle works on */
+/* ---- multi-GPU: the exchange step inside the library ----------------------------
+ * No counterpart in the reference (it is one process on one CPU thread, S3P:1107). One process per
+ * GPU, one sharded handle per process. Rank 0 calls pf_comm_unique_id (128 bytes) and hands the id
+ * to the other ranks by whatever channel the host program has; every rank then calls pf_comm_init.
+ * After that pf_weights(h, NULL) all-gathers the scores (8 B per particle) and pf_resample(h, u,
+ * NULL, ...) all-gathers the pose blocks (72 B per particle) itself, with RCCL on the handle's
+ * stream. RCCL is loaded at run time (librccl.so.1); PF_ERR_NODEVICE when it is not there. */
+int pf_comm_unique_id(void* id_out, int64_t capacity);
+int pf_comm_init(pf_handle* h, const void* id, int32_t rank, int32_t world);
+
 /* Make the handle enqueue on the CALLER's hipStream_t (e.g. the stream its RCCL collectives
  * are ordered against), so that hand-offs need no host synchronisation; NULL returns to the
  * handle's own stream. The caller keeps ownership of its stream. */

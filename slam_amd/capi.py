@@ -25,7 +25,7 @@ SYMBOLS = (
     "pf_poses_device pf_set_scan pf_update_map pf_scan_vote pf_write_local_map pf_read_local_map "
     "pf_reset_local_map pf_stream pf_set_stream pf_synchronize pf_profile pf_kernel_time "
     "pfh_snapshot_beams pfh_predict pfh_draw_noise pfh_draw_uniform pfh_add_points_policy "
-    "pfh_permute pfh_vote_hypothesis").split()
+    "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init").split()
 
 
 class Config(C.Structure):
@@ -128,6 +128,13 @@ class Handle:
         x, y, z, yaw = (_c(a, np.float64) for a in (x, y, z, yaw))
         assert len(x) == len(y) == len(z) == len(yaw) == self.P
         self._ck(lib().pf_predict(self._h, _p(x), _p(y), _p(z), _p(yaw)), "pf_predict")
+
+    def comm_init(self, unique_id, rank, world):
+        """RCCL communicator for the in-library all-gathers; unique_id: bytes from comm_unique_id()
+        of rank 0. Raises when RCCL is not loadable or the init fails."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._ck(lib().pf_comm_init(self._h, buf, int(rank), int(world)), "pf_comm_init")
+        self.native_comm = True
 
     def predict_device(self, pose_block_ptr):
         self._ck(lib().pf_predict_device(self._h, C.c_void_p(pose_block_ptr)), "pf_predict_device")
@@ -335,6 +342,14 @@ def vote_hypothesis(index, pos, zyx, resolution=0.05, n_yaw=5, yaw_k0=-6, yaw_ks
     rc = lib().pfh_vote_hypothesis(C.c_int64(int(index)), _p(pos), _p(zyx), C.c_double(resolution),
                                    n_yaw, yaw_k0, yaw_kstep, n_t, C.c_double(length), _p(out))
     return out if rc == 0 else None
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    rc = lib().pf_comm_unique_id(buf, C.c_int64(128))
+    if rc != 0:
+        raise RuntimeError(f"pf_comm_unique_id failed ({rc}): {lib().pf_last_error(None).decode()}")
+    return buf.raw
 
 
 def permute(slot_anc, records):

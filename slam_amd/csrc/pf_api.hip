@@ -2,6 +2,8 @@
 // HIP-only by design: there is no CPU path in this library.
 #include "../../include/slam_pf.h"
 #include "pf_kernels.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <math.h>
 #include <stdarg.h>
@@ -101,6 +103,12 @@ struct pf_handle {
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
     bool side_pending = false;
     bool use_side = false;
+    // RCCL communicator of a sharded handle (pf_comm_init): the two all-gathers of the step are
+    // then enqueued by pf_weights / pf_resample themselves, on the handle's stream
+    ncclComm_t comm = nullptr;
+    int comm_world = 1;
+    int2* scores_all = nullptr;        // [Pg]
+    double* poses_all = nullptr;       // [world][9][P]
     // profiling
     bool profile = false;
     unsigned profile_mask = ~0u;       // bit k: time kernel class k
@@ -173,6 +181,36 @@ hipError_t run_graph(pf_handle* h, pf_handle::GraphSlot& slot, const void* key, 
     }
     slot.key = key;
     return hipGraphLaunch(slot.exec, h->stream);
+}
+
+// RCCL is bound at run time (dlopen), so the library loads on hosts without it and a one-GPU
+// caller never touches it.
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return r;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
+    return r;
 }
 
 struct Timed {
@@ -250,6 +288,9 @@ void pf_destroy(pf_handle* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : h->ev) for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
+    if (h->scores_all) (void)hipFree(h->scores_all);
+    if (h->poses_all) (void)hipFree(h->poses_all);
     if (h->g_weights.exec) (void)hipGraphExecDestroy(h->g_weights.exec);
     if (h->g_resample.exec) (void)hipGraphExecDestroy(h->g_resample.exec);
     if (h->h_result) (void)hipHostFree(h->h_result);
@@ -688,11 +729,18 @@ int pf_voxel_indices(pf_handle* h, int32_t i, int32_t* flat_out) {
 int pf_weights(pf_handle* h, const void* scores_global_dev) {
     if (!h) return PF_ERR_ARG;
     if (!scores_global_dev) {
-        if (h->Pg != h->P) return fail(h, PF_ERR_ARG, "pf_weights: sharded handle needs the gathered scores");
+        if (h->Pg != h->P && !h->comm)
+            return fail(h, PF_ERR_ARG, "pf_weights: sharded handle needs the gathered scores (or pf_comm_init)");
         if (!h->measured) return fail(h, PF_ERR_STATE, "pf_weights before pf_measure");
     }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const int2* sc = scores_global_dev ? (const int2*)scores_global_dev : h->scores;
+    if (!scores_global_dev && h->comm) {              // C1: 8 B per particle, rank order
+        const ncclResult_t r = rccl().AllGather(h->scores, h->scores_all, 2 * (size_t)h->P, ncclInt32,
+                                                h->comm, h->stream);
+        if (r != ncclSuccess) return fail(h, PF_ERR_HIP, "pf_weights: ncclAllGather: %s", rccl().GetErrorString(r));
+        sc = h->scores_all;
+    }
     {
         Timed t(h, PF_K_WEIGHTS);
         HIP_TRY(h, run_graph(h, h->g_weights, sc, [&] {
@@ -709,9 +757,15 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
     if (!h) return PF_ERR_ARG;
     if (!h->weighted) return fail(h, PF_ERR_STATE, "pf_resample before pf_weights");
     if (!u && !h->have_u) return fail(h, PF_ERR_ARG, "pf_resample: no thresholds resident");
-    if (h->Pg != h->P && !poses_global_dev)
-        return fail(h, PF_ERR_ARG, "pf_resample: sharded handle needs the gathered pose blocks");
+    if (h->Pg != h->P && !poses_global_dev && !h->comm)
+        return fail(h, PF_ERR_ARG, "pf_resample: sharded handle needs the gathered pose blocks (or pf_comm_init)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!poses_global_dev && h->comm) {               // C2: the 72-B pose blocks, rank order
+        const ncclResult_t r = rccl().AllGather(h->pose, h->poses_all, PF_POSE_ROWS * (size_t)h->P,
+                                                ncclFloat64, h->comm, h->stream);
+        if (r != ncclSuccess) return fail(h, PF_ERR_HIP, "pf_resample: ncclAllGather: %s", rccl().GetErrorString(r));
+        poses_global_dev = h->poses_all;
+    }
     if (u) {
         HIP_TRY(h, hipMemcpyAsync(h->u, u, sizeof(double) * (size_t)h->Pg, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -915,6 +969,39 @@ int pf_reset_local_map(pf_handle* h) {
     NEED(h, h->local, "no local map");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemsetAsync(h->local, 0, (size_t)h->local_elements, h->stream));
+    return PF_OK;
+}
+
+int pf_comm_unique_id(void* id_out, int64_t capacity) {
+    if (!id_out || capacity < (int64_t)sizeof(ncclUniqueId))
+        return fail(nullptr, PF_ERR_ARG, "pf_comm_unique_id: needs %d bytes", (int)sizeof(ncclUniqueId));
+    if (!rccl().ok) return fail(nullptr, PF_ERR_NODEVICE, "pf_comm_unique_id: librccl not loadable");
+    ncclUniqueId id;
+    const ncclResult_t r = rccl().GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, PF_ERR_HIP, "ncclGetUniqueId: %s", rccl().GetErrorString(r));
+    memcpy(id_out, &id, sizeof id);
+    return PF_OK;
+}
+
+int pf_comm_init(pf_handle* h, const void* id, int32_t rank, int32_t world) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, id && world >= 1 && rank >= 0 && rank < world, "id / rank / world");
+    NEED(h, (long long)h->P * world == h->Pg && h->offset == rank * h->P,
+         "shards must be equal contiguous blocks: n_particles * world == n_particles_global, particle_offset == rank * n_particles");
+    NEED(h, h->cfg.map_mode == PF_MAP_SHARED || world == 1, "per-particle maps are single-handle");
+    NEED(h, !h->comm, "communicator already set");
+    if (!rccl().ok) return fail(h, PF_ERR_NODEVICE, "pf_comm_init: librccl not loadable");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    const ncclResult_t r = rccl().CommInitRank(&h->comm, world, uid, rank);
+    if (r != ncclSuccess) {
+        h->comm = nullptr;
+        return fail(h, PF_ERR_HIP, "ncclCommInitRank: %s", rccl().GetErrorString(r));
+    }
+    h->comm_world = world;
+    HIP_TRY(h, dalloc(&h->scores_all, (size_t)h->Pg));
+    HIP_TRY(h, dalloc(&h->poses_all, PF_POSE_ROWS * (size_t)h->Pg));
     return PF_OK;
 }
 

@@ -16,9 +16,13 @@ import numpy as np
 
 
 class ShardedBackend:
-    def __init__(self, handle, dist, group=None):
+    def __init__(self, handle, dist, group=None, native=True):
         """handle: slam_amd.capi.Handle created with n_particles = shard size,
-        n_particles_global, particle_offset = rank * shard size. dist: torch.distributed."""
+        n_particles_global, particle_offset = rank * shard size. dist: torch.distributed.
+        native: let the library do the two all-gathers itself with RCCL on its own stream
+        (pf_comm_init; torch.distributed then only carries the communicator id at set-up). Used
+        when the backend is nccl and every rank managed to create its communicator; otherwise the
+        collectives go through torch.distributed, as they do on gloo."""
         import torch
         self.torch = torch
         self.h = handle
@@ -39,6 +43,29 @@ class ShardedBackend:
                                        device=s.device)
         self._poses_all = torch.empty((self.world * p.shape[0], p.shape[1]), dtype=p.dtype,
                                       device=p.device)
+        self.native = False
+        if native and hasattr(handle, "comm_init") and dist.get_backend(group) == "nccl":
+            self.native = self._init_native()
+
+    def _init_native(self):
+        from . import capi
+        torch, dist = self.torch, self.dist
+        ok = 1
+        try:
+            box = [capi.comm_unique_id() if self.rank == 0 else None]
+        except Exception:
+            box, ok = [None], 0
+        src = dist.get_global_rank(self.group, 0) if self.group else 0
+        dist.broadcast_object_list(box, src=src, group=self.group)
+        if box[0] is None:
+            return False                      # rank 0 has no RCCL: every rank sees that
+        try:
+            self.h.comm_init(box[0], self.rank, self.world)
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self._scores_all.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
 
     # pass-through (local, no communication)
     def set_beams(self, *a): self.h.set_beams(*a)
@@ -65,12 +92,16 @@ class ShardedBackend:
             self._sync_device(t)
 
     def weights(self):
+        if self.native:
+            return self.h.weights(None)       # C1 inside the library
         self._before_collective()
         self.dist.all_gather_into_tensor(self._scores_all, self._scores, group=self.group)   # C1
         self._after_collective(self._scores_all)
         self.h.weights(self._scores_all.data_ptr())
 
     def resample(self, u=None, want_slots=True):
+        if self.native:
+            return self.h.resample(u, None, want_slots)   # C2 inside the library
         self._before_collective()
         self.dist.all_gather_into_tensor(self._poses_all, self._poses, group=self.group)     # C2
         self._after_collective(self._poses_all)

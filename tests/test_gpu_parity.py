@@ -525,9 +525,10 @@ def test_per_particle_fuse_with_collisions_matches_oracle():
 
 
 def test_sharded_backend_on_rccl_single_rank():
-    """The multi-GPU code path (slam_amd/sharded.py: zero-copy torch views of the library's
-    device buffers, all_gather_into_tensor on the nccl = RCCL backend, gathered pointers into
-    pf_weights / pf_resample) with the one rank this box has: must equal the plain handle."""
+    """The multi-GPU code paths with the one rank this box has, both must equal the plain handle:
+    "torch": slam_amd/sharded.py's zero-copy views of the library's device buffers,
+    all_gather_into_tensor on the nccl = RCCL backend, gathered pointers into pf_weights /
+    pf_resample; "native": pf_comm_init, the all-gathers enqueued by the library itself."""
     import torch
     import torch.distributed as dist
     from slam_amd.sharded import ShardedBackend
@@ -542,9 +543,11 @@ def test_sharded_backend_on_rccl_single_rank():
         sc = synth.scene(dims, P, M, seed=31)
         u = capi.draw_uniform(8, P)
         out = []
-        for sharded in (False, True):
+        for sharded in (False, "torch", "native"):
             h = capi.Handle(_shared_cfg(P, dims))
-            be = ShardedBackend(h, dist) if sharded else h
+            be = ShardedBackend(h, dist, native=sharded == "native") if sharded else h
+            if sharded:
+                assert be.native == (sharded == "native")
             try:
                 h.write_map(0, sc["grid"]); be.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
                 be.set_beams(*sc["beams"]); be.measure(0); be.weights()
@@ -556,8 +559,9 @@ def test_sharded_backend_on_rccl_single_rank():
                     assert bp == tuple(np.stack(h.get_poses())[:, r[1]])
             finally:
                 h.close()
-        for a, b in zip(out[0], out[1]):
-            assert np.array_equal(a, b)
+        for other in out[1:]:
+            for a, b in zip(out[0], other):
+                assert np.array_equal(a, b)
     finally:
         if created:
             dist.destroy_process_group()

@@ -68,6 +68,120 @@ __global__ __launch_bounds__(256) void k_measure(
 }
 
 // ------------------------------------------------------------------------------------------
+// K1+K2 on per-particle maps, one WAVE per particle, lanes over 64 consecutive beams.
+// k_measure<true> gives every lane its own 2 MiB slab, so a wave-wide access touches 64 lines
+// for 64 bytes and the launch moves 128 B of HBM per evaluation (measured 2.0 ms for configs[3],
+// i.e. 6.5 TB/s of line traffic). Here the 64 lanes of a wave work on ONE slab and consecutive
+// beams (S3P:868 order: z fastest) fall into the same or neighbouring lines.
+// The reference walks the beams of a particle one after the other (S3P:868-904): a beam reads
+// the cell AFTER every earlier beam of the same particle that rounds to the same cell has added
+// to it. Order only matters between such colliding beams, so each batch of 64 is settled in
+// rounds: per round the lowest pending lane of every distinct cell is elected through a small
+// LDS hash table keyed by the flat index (exact: keys are compared in full) and those winners
+// read-modify-write in parallel; lanes that lost wait for the next round. Cells are read with
+// L2-coherent loads after the previous round's / batch's stores were acknowledged, so a later
+// beam sees the earlier add whichever lane made it.
+// ------------------------------------------------------------------------------------------
+#define FUSE_K 4                  // beams per lane and batch: 256 beams settle together
+#define FUSE_TBL 512
+#define FUSE_EMPTY 0xffffffffu
+__global__ __launch_bounds__(256) void k_measure_fuse_wave(
+        const double* __restrict__ pose, int P, uint8_t* maps, unsigned long long map_stride,
+        const PfBeam* __restrict__ beams, int M, PfGridParams gp, int2* __restrict__ partial) {
+    __shared__ unsigned keys[4][FUSE_TBL];
+    __shared__ unsigned minl[4][FUSE_TBL];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+    if (p >= P) return;                                   // wave-uniform; no block barrier below
+    for (int k = lane; k < FUSE_TBL; k += 64) {
+        __hip_atomic_store(&keys[wv][k], FUSE_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_store(&minl[wv][k], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double c = pose[4 * (size_t)P + p], s = pose[5 * (size_t)P + p];
+    const double tx = pose[6 * (size_t)P + p], ty = pose[7 * (size_t)P + p];
+    const double tz = pose[8 * (size_t)P + p];
+    const double ms = -s;
+    uint8_t* map = maps + map_stride * (unsigned long long)p;
+    int sum = 0, cnt = 0;
+    for (int j0 = 0; j0 < M; j0 += 64 * FUSE_K) {
+        // beam j0 + 64 k + lane: its place in the reference's order inside the batch is 64 k + lane
+        bool pending[FUSE_K];
+        unsigned f[FUSE_K], slot[FUSE_K];
+        int v[FUSE_K];
+        bool any_pending = false;
+#pragma unroll
+        for (int k = 0; k < FUSE_K; ++k) {
+            const int j = j0 + 64 * k + lane;
+            pending[k] = false; f[k] = 0; v[k] = 0; slot[k] = 0;
+            if (j < M) {
+                const PfBeam b = beams[j];
+                const double X = round((c * b.lx + ms * b.ly) + tx);   // S3P:745-747, 880, 85
+                const double Y = round((s * b.lx + c * b.ly) + ty);
+                const double Z = round(b.lz + tz);
+                const double fd = fma(X, gp.gyz, fma(Y, gp.gzd, Z));
+                pending[k] = fd >= 0.0 && fd < gp.elements;            // S3P:882
+                f[k] = pending[k] ? (unsigned)(int)fd : 0u;
+                v[k] = b.v;
+            }
+            any_pending |= pending[k];
+        }
+        while (__any(any_pending)) {
+#pragma unroll
+            for (int k = 0; k < FUSE_K; ++k) {
+                if (!pending[k]) continue;
+                unsigned sl = (f[k] * 2654435761u) >> 23;
+                while (true) {
+                    const unsigned old = atomicCAS(&keys[wv][sl], FUSE_EMPTY, f[k]);
+                    if (old == FUSE_EMPTY || old == f[k]) break;
+                    sl = (sl + 1u) & (FUSE_TBL - 1u);
+                }
+                atomicMin(&minl[wv][sl], (unsigned)(64 * k + lane));
+                slot[k] = sl;
+            }
+            __builtin_amdgcn_wave_barrier();
+            bool winner[FUSE_K];
+#pragma unroll
+            for (int k = 0; k < FUSE_K; ++k)
+                winner[k] = pending[k] && __hip_atomic_load(&minl[wv][slot[k]], __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_WAVEFRONT) == (unsigned)(64 * k + lane);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < FUSE_K; ++k)
+                if (pending[k]) {                                      // leave the table empty again
+                    __hip_atomic_store(&keys[wv][slot[k]], FUSE_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_store(&minl[wv][slot[k]], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            __builtin_amdgcn_wave_barrier();
+            unsigned w[FUSE_K];
+#pragma unroll
+            for (int k = 0; k < FUSE_K; ++k)
+                if (winner[k])
+                    w[k] = __hip_atomic_load((const unsigned*)(map + (f[k] & ~3u)), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+            any_pending = false;
+#pragma unroll
+            for (int k = 0; k < FUSE_K; ++k) {
+                if (winner[k]) {
+                    const int cell = (int)((w[k] >> (8u * (f[k] & 3u))) & 0xffu);
+                    if (v[k] > gp.occ_threshold) { sum += cell; cnt += 1; }   // S3P:886-889
+                    int nv = cell + v[k];                                  // S3P:895-904
+                    nv = nv < gp.lo ? gp.lo : (nv > gp.hi ? gp.hi : nv);
+                    if (nv != cell) map[f[k]] = (uint8_t)nv;
+                    pending[k] = false;
+                }
+                any_pending |= pending[k];
+            }
+            // the stores of this round reach L2 before any later load of this wave is issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); cnt += __shfl_xor(cnt, o, 64); }
+    if (lane == 0) partial[p] = make_int2(sum, cnt);
+}
+
+// ------------------------------------------------------------------------------------------
 // K1 fast form (no fuse): the same lane-per-particle mapping with a floating-point FILTER in
 // front of the fp64 arithmetic. The voxel coordinate is first evaluated in fp32 (2 FMAs per
 // axis at full VALU rate instead of 4 half-rate fp64 operations plus a 6-instruction fp64
@@ -380,7 +494,12 @@ hipError_t pfk_measure(hipStream_t st, const double* pose, int P, uint8_t* maps,
                        unsigned long long map_stride, const PfBeam* beams, int M, int n_chunks,
                        int bpc, PfGridParams gp, bool fuse, int2* partial) {
     dim3 grid((P + 255) / 256, n_chunks);
-    if (fuse)
+    // SLAM_PF_FUSE_LANE=1: the lane-per-particle fuse kernel (development comparison)
+    static const bool fuse_lane = getenv("SLAM_PF_FUSE_LANE") && atoi(getenv("SLAM_PF_FUSE_LANE")) != 0;
+    if (fuse && !fuse_lane && gp.elements < 2147483648.0)
+        hipLaunchKernelGGL(k_measure_fuse_wave, dim3((P + 3) / 4), dim3(256), 0, st, pose, P, maps,
+                           map_stride, beams, M, gp, partial);
+    else if (fuse)
         hipLaunchKernelGGL(k_measure<true>, grid, dim3(256), 0, st, pose, P, maps, map_stride,
                            beams, M, bpc, gp, partial);
     else

@@ -54,6 +54,7 @@ struct pf_handle {
     double lmax_occ = 0;               // max over occupied beams of max(|lx|+|ly|, |lz|)
     int2* partial = nullptr;           // [max_chunks][P]
     int2* scores = nullptr;            // [P]
+    int32_t* bmin = nullptr;           // [ceil(P/256)] block minima of scores (pfk_reduce_scores)
     int32_t* draw = nullptr;           // [Pg]
     int32_t* first = nullptr;          // [Pg]
     int32_t* dup_anc = nullptr;        // [Pg]
@@ -282,7 +283,7 @@ void pf_destroy(pf_handle* h) {
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
-    void* ptrs[] = {h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_occ_g,
+    void* ptrs[] = {h->bmin, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_occ_g,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
                     h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -410,6 +411,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     if (const char* e = getenv("SLAM_PF_EXACT_MEASURE")) h->force_exact_measure = atoi(e);
     CREATE_TRY(dalloc(&h->partial, (size_t)h->max_chunks * P));
     CREATE_TRY(dalloc(&h->scores, P));
+    CREATE_TRY(dalloc(&h->bmin, (P + 255) / 256));
     CREATE_TRY(dalloc(&h->draw, Pg));
     CREATE_TRY(dalloc(&h->first, Pg));
     CREATE_TRY(dalloc(&h->dup_anc, Pg));
@@ -693,7 +695,7 @@ int pf_measure(pf_handle* h, int add_points) {
                                         h->beams_occ, Mk, chunks, bpc, grid_params(h), h->lmax_occ,
                                         h->order, h->partial));
     }
-    HIP_TRY(h, pfk_reduce_scores(h->stream, h->partial, chunks, h->P, h->scores));
+    HIP_TRY(h, pfk_reduce_scores(h->stream, h->partial, chunks, h->P, h->scores, h->bmin));
     h->measured = true;
     return PF_OK;
 }
@@ -745,7 +747,7 @@ int pf_weights(pf_handle* h, const void* scores_global_dev) {
         Timed t(h, PF_K_WEIGHTS);
         HIP_TRY(h, run_graph(h, h->g_weights, sc, [&] {
             return pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact, h->first,
-                               h->counters, h->rs);
+                               h->counters, h->rs, sc == h->scores && h->P == h->Pg ? h->bmin : nullptr);
         }));
     }
     h->weighted = true;

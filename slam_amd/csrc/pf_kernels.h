@@ -72,7 +72,9 @@ hipError_t pfk_measure_swz(hipStream_t st, const double* sorted, int P, const ui
                            PfSwz sw, const PfBeamG* bg, const PfBeam* bd, int M, int n_chunks, int bpc,
                            PfGridParams gp, double lmax, const int32_t* order, int2* partial);
 hipError_t pfk_swz_build(hipStream_t st, const uint8_t* lin, uint8_t* shadow, PfSwz sw);
-hipError_t pfk_reduce_scores(hipStream_t st, const int2* partial, int n_chunks, int P, int2* scores);
+// bmin: int32 [ceil(P/256)], the smallest sum_match of each 256-particle block
+hipError_t pfk_reduce_scores(hipStream_t st, const int2* partial, int n_chunks, int P, int2* scores,
+                             int32_t* bmin);
 hipError_t pfk_voxel_indices(hipStream_t st, const double* pose, int P, int i, const PfBeam* beams,
                              int M, PfGridParams gp, int32_t* flat_out);
 
@@ -92,9 +94,10 @@ struct PfResampleScratch {
 
 // K3: S3P:920-937. w in/out [Pg]; logw out [Pg]; cdf out [Pg+1]; scratch double [Pg+1].
 // Also initialises K4's first[Pg] table and counters[0..2] for this step.
+// bmin (may be null): pfk_reduce_scores' block minima of exactly these scores; saves the min pass.
 hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
                        double* cdf, double* scratch, bool exact, int32_t* first,
-                       unsigned long long* counters, PfResampleScratch sc);
+                       unsigned long long* counters, PfResampleScratch sc, const int32_t* bmin);
 
 // K4: S3P:757-821, the whole chain on the stream, no host round trip: search (+ re-search of
 // ambiguous draws on the sequential-order CDF when bound > 0), slot assignment, permutation of

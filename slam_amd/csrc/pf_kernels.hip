@@ -460,16 +460,26 @@ __global__ __launch_bounds__(256) void k_swz_build(const uint8_t* __restrict__ l
 
 __global__ __launch_bounds__(256) void k_reduce_scores(const int2* __restrict__ partial,
                                                        int n_chunks, int P,
-                                                       int2* __restrict__ scores) {
+                                                       int2* __restrict__ scores,
+                                                       int32_t* __restrict__ bmin) {
+    __shared__ int sh[4];
     const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
     int sx = 0, sy = 0;
+    if (p < P) {
 #pragma unroll 8
-    for (int k = 0; k < n_chunks; ++k) {
-        const int2 v = partial[(size_t)k * P + p];
-        sx += v.x; sy += v.y;
+        for (int k = 0; k < n_chunks; ++k) {
+            const int2 v = partial[(size_t)k * P + p];
+            sx += v.x; sy += v.y;
+        }
+        scores[p] = make_int2(sx, sy);
     }
-    scores[p] = make_int2(sx, sy);
+    // the block's smallest sum_match: K3 starts from these instead of a pass of its own (S3P:920-925)
+    int m = p < P ? sx : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) bmin[blockIdx.x] = min(min(sh[0], sh[1]), min(sh[2], sh[3]));
 }
 
 __global__ __launch_bounds__(256) void k_voxel_indices(const double* __restrict__ pose, int P,
@@ -641,9 +651,9 @@ hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, i
 }
 
 hipError_t pfk_reduce_scores(hipStream_t st, const int2* partial, int n_chunks, int P,
-                             int2* scores) {
+                             int2* scores, int32_t* bmin) {
     hipLaunchKernelGGL(k_reduce_scores, dim3((P + 255) / 256), dim3(256), 0, st, partial,
-                       n_chunks, P, scores);
+                       n_chunks, P, scores, bmin);
     return hipGetLastError();
 }
 

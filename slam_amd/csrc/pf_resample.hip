@@ -121,7 +121,7 @@ __device__ inline double seq_sum(const double* src, int n, double* tile, double*
     for (int base = 0; base < n; base += TILE) {
         const int cntv = min(TILE, n - base);
         __syncthreads();
-        for (int k = threadIdx.x; k < cntv; k += WG) tile[k] = src[base + k];
+        for (int k = threadIdx.x; k < cntv; k += blockDim.x) tile[k] = src[base + k];
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int k = 0; k < cntv; ++k) run += tile[k];
@@ -141,7 +141,7 @@ __device__ inline void seq_cdf(const double* w, int n, double* cdf, double* tile
     for (int base = 0; base < n; base += TILE) {
         const int cntv = min(TILE, n - base);
         __syncthreads();
-        for (int k = threadIdx.x; k < cntv; k += WG) tile[k] = w[base + k];
+        for (int k = threadIdx.x; k < cntv; k += blockDim.x) tile[k] = w[base + k];
         __syncthreads();
         if (threadIdx.x == 0) {
             double run = carry;
@@ -149,7 +149,7 @@ __device__ inline void seq_cdf(const double* w, int n, double* cdf, double* tile
             carry = run;
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < cntv; k += WG) cdf[base + 1 + k] = tile[k];
+        for (int k = threadIdx.x; k < cntv; k += blockDim.x) cdf[base + 1 + k] = tile[k];
     }
     __syncthreads();
 }
@@ -272,6 +272,36 @@ __global__ __launch_bounds__(NB) void k3_raw(const int2* __restrict__ scores, in
     d3_raw(blockIdx.x, threadIdx.x, sh, scores, Pg, w, lbuf, prm, bsum, bmax, bse);
 }
 
+// k3_raw with the min stage inside: the smallest sum comes from pfk_reduce_scores' block minima
+// (integers: any order), the three derived constants are computed by every workgroup with the
+// expressions of d3_min.
+__global__ __launch_bounds__(NB) void k3_raw_m(const int2* __restrict__ scores, int Pg, double* w,
+                                               double* __restrict__ lbuf,
+                                               const int32_t* __restrict__ bmin, int n_bmin,
+                                               double* bsum, double* bmax, double* bse) {
+    __shared__ double sh[NB / WAVE];
+    __shared__ int shi[NB / WAVE];
+    __shared__ double prm_s[8];
+    const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6;
+    int m = INT_MAX;
+    for (int k = lt; k < n_bmin; k += NB) m = min(m, bmin[k]);
+    m = wave_min_i(m);
+    if (lane == 0) shi[wv] = m;
+    __syncthreads();
+    if (lt == 0) {
+        m = shi[0];
+        for (int k = 1; k < NB / WAVE; ++k) m = min(m, shi[k]);
+        double smallest = 1000000000000.0;                 // S3P:920
+        if (smallest > (double)m) smallest = (double)m;
+        const double n_match = (double)scores[Pg - 1].y;
+        prm_s[PRM_K99] = 0.99 * smallest;
+        prm_s[PRM_N] = n_match;
+        prm_s[PRM_LOGN] = log(n_match);
+    }
+    __syncthreads();
+    d3_raw(blockIdx.x, lt, sh, scores, Pg, w, lbuf, prm_s, bsum, bmax, bse);
+}
+
 // One workgroup: S = sum of bsum (thread t adds blocks t, t+1024, ... then the fixed tree),
 // exclusive scan of bsum into boff, global max / log-sum-exp.
 __device__ inline void d3_combine(int nb, const double* bsum, const double* bmax, const double* bse,
@@ -342,6 +372,61 @@ __global__ __launch_bounds__(NB) void k3_norm(int Pg, double* w, const double* _
                                               unsigned long long* counters) {
     __shared__ double sh[NB / WAVE];
     d3_norm(blockIdx.x, threadIdx.x, sh, Pg, w, lbuf, logw, prm, boff, cdf, first, counters);
+}
+
+// k3_norm with the combine stage inside: for up to 1024 blocks (262 144 particles) the combine is
+// a scan over at most 1024 block partials, cheaper to redo in every workgroup than to launch
+// (a launch boundary costs ~4 us here, the redundant scan well under one). The 256 threads walk
+// the 16 wave-shaped pieces of k3_combine's 1024-thread arithmetic in four passes, same
+// shuffles, same order of the wave totals: bit-identical to the separate kernel.
+__global__ __launch_bounds__(NB) void k3_norm_c(int Pg, int nb, double* w, const double* lbuf,
+                                                float* __restrict__ logw, const double* bsum,
+                                                const double* bmax, const double* bse, double* cdf,
+                                                int32_t* __restrict__ first,
+                                                unsigned long long* counters) {
+    __shared__ double shT[WG / WAVE], shM[WG / WAVE], shS[WG / WAVE];
+    __shared__ double sh4[NB / WAVE];
+    __shared__ double prm_s[8], s_boff;
+    const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6, vb = blockIdx.x;
+    double loc[4], inc[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int vw = pass * 4 + wv, vt = vw * 64 + lane;
+        loc[pass] = vt < nb ? bsum[vt] : 0.0;
+        double m = -INFINITY;
+        if (vt < nb) m = fmax(m, bmax[vt]);
+        inc[pass] = wave_scan(loc[pass]);
+        m = wave_max(m);
+        if (lane == 63) shT[vw] = inc[pass];
+        if (lane == 0) shM[vw] = m;
+    }
+    __syncthreads();
+    double total = 0;
+    for (int k = 0; k < WG / WAVE; ++k) total += shT[k];
+    double gmax = shM[0];
+    for (int k = 1; k < WG / WAVE; ++k) gmax = fmax(gmax, shM[k]);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int vw = pass * 4 + wv, vt = vw * 64 + lane;
+        double se = 0;
+        if (vt < nb) se += bmax[vt] > -INFINITY ? bse[vt] * exp(bmax[vt] - gmax) : 0.0;
+        se = wave_sum(se);
+        if (lane == 0) shS[vw] = se;
+        if (vt == vb) {                                   // this workgroup's offset in the scan
+            double woff = 0;
+            for (int k = 0; k < vw; ++k) woff += shT[k];
+            s_boff = woff + inc[pass] - loc[pass];
+        }
+    }
+    __syncthreads();
+    if (lt == 0) {
+        double se = 0;
+        for (int k = 0; k < WG / WAVE; ++k) se += shS[k];
+        prm_s[PRM_S] = total;
+        prm_s[PRM_LSE] = gmax + log(se);
+    }
+    __syncthreads();
+    d3_norm(vb, lt, sh4, Pg, w, lbuf, logw, prm_s, &s_boff - vb, cdf, first, counters);
 }
 
 // K3 in ONE workgroup for up to PF_MID_MAX particles: the same four stages on the same 256-
@@ -501,6 +586,38 @@ __global__ __launch_bounds__(NB) void k4_scatter(const int32_t* __restrict__ dra
     __shared__ int sd[NB / WAVE], sf[NB / WAVE];
     (void)free_slot;
     d4_scatter(blockIdx.x, threadIdx.x, sd, sf, draw, Pg, first, boff, dup_anc, slot_anc);
+}
+// k4_scatter with the scan of the block counts inside (integers: any order of addition gives the
+// same offsets), for up to 1024 blocks.
+__global__ __launch_bounds__(NB) void k4_scatter_s(const int32_t* __restrict__ draw, int Pg,
+                                                   const int32_t* __restrict__ first,
+                                                   const int2* __restrict__ bcnt,
+                                                   int32_t* __restrict__ dup_anc,
+                                                   int32_t* __restrict__ slot_anc) {
+    __shared__ int sd[NB / WAVE], sf[NB / WAVE];
+    __shared__ int2 my_off;
+    const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6, vb = blockIdx.x;
+    int a = 0, b = 0;
+    for (int k = lt; k < vb; k += NB) { const int2 c = bcnt[k]; a += c.x; b += c.y; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, WAVE); b += __shfl_xor(b, o, WAVE); }
+    if (lane == 0) { sd[wv] = a; sf[wv] = b; }
+    __syncthreads();
+    if (lt == 0) my_off = make_int2(sd[0] + sd[1] + sd[2] + sd[3], sf[0] + sf[1] + sf[2] + sf[3]);
+    __syncthreads();
+    d4_scatter(vb, lt, sd, sf, draw, Pg, first, &my_off - vb, dup_anc, slot_anc);
+}
+// k_first with the rare sequential-order CDF inside: when draws were ambiguous every workgroup
+// rebuilds the CDF itself (all write the same values) before it searches again.
+__global__ __launch_bounds__(NB) void k_first_c(double* cdf, const double* __restrict__ u,
+                                                int32_t* draw, int Pg, const double* w,
+                                                int32_t* first, unsigned long long* counters) {
+    __shared__ double tile[TILE];
+    if (ld_agent(&counters[1]) != 0) {                     // uniform over the whole grid
+        seq_cdf(w, Pg, cdf, tile);
+        __syncthreads();
+    }
+    d_first(blockIdx.x * NB + threadIdx.x, cdf, u, draw, Pg, first, counters);
 }
 // S3P:805-812 + the first stage of S3P:814-820. Sources are slots that keep themselves, so the
 // in-place parallel copy reads nothing that this stage writes. Per block: the first index of
@@ -673,6 +790,11 @@ __global__ __launch_bounds__(NB) void k_apply_maps(const int32_t* __restrict__ s
 // launchers
 // ------------------------------------------------------------------------------------------
 static inline int nblocks(int n) { return (n + NB - 1) / NB; }
+// SLAM_PF_CHAIN=1: every stage its own launch (the form the folded kernels are tested against)
+static inline bool chain_only() {
+    const char* e = getenv("SLAM_PF_CHAIN");
+    return e && atoi(e) != 0;
+}
 // SLAM_PF_MID=1: K3 and K4 as ONE workgroup each (k3_mid, k4_mid) instead of the multi-kernel
 // chains. Off by default: one CU cannot hide the latency of 10k binary searches, measured 67 us
 // (K3) and 172 us (K4) against 18 and 29 us for the chains at 10k particles. Kept because the
@@ -685,7 +807,7 @@ static inline bool mid_ok(int Pg) {
 
 hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
                        double* cdf, double* scratch, bool exact, int32_t* first,
-                       unsigned long long* counters, PfResampleScratch sc) {
+                       unsigned long long* counters, PfResampleScratch sc, const int32_t* bmin) {
     if (exact) {
         hipLaunchKernelGGL(k_weights_exact, dim3(1), dim3(WG), 0, st, scores, Pg, w, logw, cdf, scratch,
                            first, counters);
@@ -697,9 +819,19 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
                            counters, sc);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k3_min, dim3(1), dim3(WG), 0, st, scores, Pg, sc.prm);
-    hipLaunchKernelGGL(k3_raw, dim3(nb), dim3(NB), 0, st, scores, Pg, w, scratch, sc.prm, sc.bsum,
-                       sc.bmax, sc.bse);
+    if (bmin && !chain_only()) {
+        hipLaunchKernelGGL(k3_raw_m, dim3(nb), dim3(NB), 0, st, scores, Pg, w, scratch, bmin, nb, sc.bsum,
+                           sc.bmax, sc.bse);
+    } else {
+        hipLaunchKernelGGL(k3_min, dim3(1), dim3(WG), 0, st, scores, Pg, sc.prm);
+        hipLaunchKernelGGL(k3_raw, dim3(nb), dim3(NB), 0, st, scores, Pg, w, scratch, sc.prm, sc.bsum,
+                           sc.bmax, sc.bse);
+    }
+    if (nb <= WG && !chain_only()) {
+        hipLaunchKernelGGL(k3_norm_c, dim3(nb), dim3(NB), 0, st, Pg, nb, w, scratch, logw, sc.bsum, sc.bmax,
+                           sc.bse, cdf, first, counters);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k3_combine, dim3(1), dim3(WG), 0, st, nb, sc.bsum, sc.bmax, sc.bse, sc.boff, sc.prm);
     hipLaunchKernelGGL(k3_norm, dim3(nb), dim3(NB), 0, st, Pg, w, scratch, logw, sc.prm, sc.boff, cdf,
                        first, counters);
@@ -721,16 +853,25 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
                            draw, first, dup_anc, slot_anc, best, counters, sc, host_out);
         return hipGetLastError();
     }
+    const bool folded = nb <= WG && !chain_only();
     hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, bound, draw, counters);
-    if (bound > 0.0)
-        // settle draws that sit within the parallel CDF's rounding error of a boundary on the
-        // sequential-order CDF of the same weights (returns at once when there are none)
-        hipLaunchKernelGGL(k_cdf_exact_if, dim3(1), dim3(WG), 0, st, w, Pg, (double*)cdf, counters);
-    hipLaunchKernelGGL(k_first, dim3(nb), dim3(NB), 0, st, cdf, u, draw, Pg, first, counters);
+    // draws that sit within the parallel CDF's rounding error of a boundary are settled on the
+    // sequential-order CDF of the same weights (nothing happens when there are none)
+    if (folded) {
+        hipLaunchKernelGGL(k_first_c, dim3(nb), dim3(NB), 0, st, (double*)cdf, u, draw, Pg, w, first, counters);
+    } else {
+        if (bound > 0.0)
+            hipLaunchKernelGGL(k_cdf_exact_if, dim3(1), dim3(WG), 0, st, w, Pg, (double*)cdf, counters);
+        hipLaunchKernelGGL(k_first, dim3(nb), dim3(NB), 0, st, cdf, u, draw, Pg, first, counters);
+    }
     hipLaunchKernelGGL(k4_count, dim3(nb), dim3(NB), 0, st, draw, Pg, first, sc.bcnt);
-    hipLaunchKernelGGL(k4_scan, dim3(1), dim3(WG), 0, st, nb, sc.bcnt, sc.boff2, sc.ndup);
-    hipLaunchKernelGGL(k4_scatter, dim3(nb), dim3(NB), 0, st, draw, Pg, first, sc.boff2, dup_anc,
-                       free_slot, slot_anc);
+    if (folded) {
+        hipLaunchKernelGGL(k4_scatter_s, dim3(nb), dim3(NB), 0, st, draw, Pg, first, sc.bcnt, dup_anc, slot_anc);
+    } else {
+        hipLaunchKernelGGL(k4_scan, dim3(1), dim3(WG), 0, st, nb, sc.bcnt, sc.boff2, sc.ndup);
+        hipLaunchKernelGGL(k4_scatter, dim3(nb), dim3(NB), 0, st, draw, Pg, first, sc.boff2, dup_anc,
+                           free_slot, slot_anc);
+    }
     if (P == Pg && !pose_gathered) {
         hipLaunchKernelGGL(k4_apply<true>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
                            pose, sc.bbest_v, sc.bbest_i);

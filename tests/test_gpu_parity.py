@@ -199,8 +199,8 @@ def test_shared_grid_fast_order_large(P):
         h.close()
 
 
-def test_fast_order_one_workgroup_equals_kernel_chain(monkeypatch):
-    """The single-workgroup K3/K4 (SLAM_PF_MID=1, a development form) and the multi-kernel chains are the same
+def test_fast_order_forms_are_bit_identical(monkeypatch):
+    """The three launch forms of K3/K4 in FAST order (folded, chain, single workgroup) are the same
     arithmetic on the same 256-particle blocks: every output bit-identical, also when draws sit
     on CDF boundaries (the re-search path)."""
     P, M, dims = 7001, 256, (64, 64, 64)
@@ -208,8 +208,11 @@ def test_fast_order_one_workgroup_equals_kernel_chain(monkeypatch):
     rng = np.random.default_rng(5)
     w0 = rng.random(P) + 1e-3; w0 /= w0.sum()
     out = []
-    for mid in ("1", "0"):
+    # default = stages folded into their neighbours; CHAIN = every stage its own launch;
+    # MID = one workgroup per chain
+    for mid, chain in (("0", "0"), ("0", "1"), ("1", "0")):
         monkeypatch.setenv("SLAM_PF_MID", mid)
+        monkeypatch.setenv("SLAM_PF_CHAIN", chain)
         h = capi.Handle(_shared_cfg(P, dims, order_mode=capi.PF_ORDER_FAST))
         try:
             h.write_map(0, sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
@@ -226,12 +229,13 @@ def test_fast_order_one_workgroup_equals_kernel_chain(monkeypatch):
             out.append((gw, glw, slots, gbest, gnohit, amb, gw2, glw2, h.get_poses()))
         finally:
             h.close()
-    a, b = out
+    a = out[0]
     assert a[5] > 0                                           # the re-search path did run
-    for x, y in zip(a[:8], b[:8]):
-        assert np.array_equal(x, y)
-    for x, y in zip(a[8], b[8]):
-        assert np.array_equal(x, y)
+    for b in out[1:]:
+        for x, y in zip(a[:8], b[:8]):
+            assert np.array_equal(x, y)
+        for x, y in zip(a[8], b[8]):
+            assert np.array_equal(x, y)
 
 
 def test_systematic_thresholds_same_kernel():

@@ -72,6 +72,8 @@ struct pf_handle {
     int32_t* order_hist[2] = {nullptr, nullptr};   // [PF_ORDER_BUCKETS] each, used alternately
     int order_flip = 0;
     bool order_dirty = true;           // poses changed since order[] was built
+    bool hist_counted = false;         // order_keys / order_hist[0] already hold the current poses' keys
+                                       // (pf_resample's fill stage counted them)
     double* points = nullptr;          // [max_points][3]
     double* wpts = nullptr;            // [max_points][3]
     int32_t* ray_idx = nullptr;        // [max_points]
@@ -182,6 +184,13 @@ hipError_t run_graph(pf_handle* h, pf_handle::GraphSlot& slot, const void* key, 
     }
     slot.key = key;
     return hipGraphLaunch(slot.exec, h->stream);
+}
+
+// The poses the last pf_resample counted K1's order keys for are being replaced.
+hipError_t drop_counted_keys(pf_handle* h) {
+    if (!h->hist_counted) return hipSuccess;
+    h->hist_counted = false;
+    return hipMemsetAsync(h->order_hist[0], 0, sizeof(int32_t) * 4096, h->stream);
 }
 
 // RCCL is bound at run time (dlopen), so the library loads on hosts without it and a one-GPU
@@ -479,6 +488,7 @@ int pf_predict(pf_handle* h, const double* x, const double* y, const double* z, 
     upload_pose_rows(h, x, y, z, yaw);
     HIP_TRY(h, hipMemcpyAsync(h->pose, h->h_pose.data(), sizeof(double) * PF_POSE_ROWS * h->P,
                               hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, drop_counted_keys(h));
     h->order_dirty = true;
     return PF_OK;
 }
@@ -489,6 +499,7 @@ int pf_predict_device(pf_handle* h, const void* pose_block_dev) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemcpyAsync(h->pose, pose_block_dev, sizeof(double) * PF_POSE_ROWS * h->P,
                               hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, drop_counted_keys(h));
     h->order_dirty = true;
     return PF_OK;
 }
@@ -666,12 +677,20 @@ int pf_measure(pf_handle* h, int add_points) {
         bpc = (bpc + PF_BEAM_GROUP - 1) / PF_BEAM_GROUP * PF_BEAM_GROUP;
         chunks = (Mk + bpc - 1) / bpc;
     }
+    const PfOrderParams op = order_params(h);
+    const bool small_keys = op.mode != 0 && op.bits == 4;      // 4096 buckets: fixed counter pair
     if (!fuse && !h->force_exact_measure && h->order_dirty) {
-        HIP_TRY(h, pfk_order(h->stream, h->pose, h->P, h->order_keys, h->order_hist[h->order_flip],
-                             h->order_hist[h->order_flip ^ 1], h->order, h->sorted, order_params(h)));
-        h->order_flip ^= 1;
+        if (small_keys) {
+            HIP_TRY(h, pfk_order(h->stream, h->pose, h->P, h->order_keys, h->order_hist[0], h->order_hist[1],
+                                 h->order, h->sorted, op, h->hist_counted));
+        } else {
+            HIP_TRY(h, pfk_order(h->stream, h->pose, h->P, h->order_keys, h->order_hist[h->order_flip],
+                                 h->order_hist[h->order_flip ^ 1], h->order, h->sorted, op, false));
+            h->order_flip ^= 1;
+        }
         h->order_dirty = false;
     }
+    h->hist_counted = false;           // consumed above, or stale: pfk_reduce_scores zeroes the pair
     HIP_TRY(h, wait_map_writes(h));      // the ordering above may overlap a running K5, K1 may not
     const bool swz = h->shadow && !fuse && !h->force_exact_measure;
     if (swz && h->shadow_dirty) {
@@ -695,7 +714,8 @@ int pf_measure(pf_handle* h, int add_points) {
                                         h->beams_occ, Mk, chunks, bpc, grid_params(h), h->lmax_occ,
                                         h->order, h->partial));
     }
-    HIP_TRY(h, pfk_reduce_scores(h->stream, h->partial, chunks, h->P, h->scores, h->bmin));
+    HIP_TRY(h, pfk_reduce_scores(h->stream, h->partial, chunks, h->P, h->scores, h->bmin, h->order_hist[0],
+                                 h->order_hist[1], small_keys ? 4096 : 0));
     h->measured = true;
     return PF_OK;
 }
@@ -779,12 +799,18 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
         // FAST order: the parallel sum/scan differs from the sequential one by at most a few
         // Pg*2^-53 per boundary (all partial sums <= ~1); 8x that as the band.
         const double bound = h->exact ? 0.0 : 8.0 * (double)h->Pg * 1.1102230246251565e-16;
+        // one GPU, shared-key ordering: the fill stage leaves K1's order keys of the new poses
+        const PfOrderParams op = order_params(h);
+        const bool count_keys = h->P == h->Pg && !poses_global_dev && op.mode != 0 && op.bits == 4 &&
+                                !h->use_graphs;
         HIP_TRY(h, run_graph(h, h->g_resample, poses_global_dev, [&] {
             return pfk_resample(h->stream, h->cdf, h->u, h->Pg, h->P, h->offset, bound, h->w, h->logw,
                                 h->pose, (const double*)poses_global_dev, h->slab ? h->maps : nullptr,
                                 h->slab, (unsigned long long)h->elements, h->draw, h->first, h->dup_anc,
-                                h->free_slot, h->slot_anc, h->best, h->counters, h->rs, h->d_result);
+                                h->free_slot, h->slot_anc, h->best, h->counters, h->rs, h->d_result,
+                                count_keys ? h->order_hist[0] : nullptr, h->order_keys, op);
         }));
+        h->hist_counted = count_keys;
     }
     if (slot_anc_out)
         HIP_TRY(h, hipMemcpyAsync(slot_anc_out, h->slot_anc, sizeof(int32_t) * (size_t)h->Pg,

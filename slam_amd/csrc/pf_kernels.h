@@ -64,17 +64,34 @@ struct PfOrderParams {
     int32_t mode;        // 0: lexicographic yaw,x,y (6/4/5 bits)  1: Morton
     int32_t bits;        // Morton: bits per axis, 4 (4096 buckets) or 5 (32768 buckets)
 };
+#ifdef __HIPCC__
+__device__ inline int pf_spread3(int v) {       // 5 bits -> every third bit
+    return (v & 1) | ((v & 2) << 2) | ((v & 4) << 4) | ((v & 8) << 6) | ((v & 16) << 8);
+}
+// K1's lane-order key of particle i of a pose block with n columns
+__device__ inline int order_key(const double* __restrict__ pose, int n, int i, PfOrderParams op) {
+    const int a = (int)floor(pose[3 * (size_t)n + i] * op.qa);
+    const int x = (int)floor(pose[6 * (size_t)n + i] * op.qx);
+    const int y = (int)floor(pose[7 * (size_t)n + i] * op.qy);
+    if (op.mode == 0) return ((a & 63) << 9) | ((x & 15) << 5) | (y & 31);
+    const int m = (1 << op.bits) - 1;                                          // Morton
+    return (pf_spread3(a & m) << 2) | (pf_spread3(x & m) << 1) | pf_spread3(y & m);
+}
+#endif
 // sorted: double [5][P] = cos, sin, x/res, y/res, z/res in lane order (K1's prologue).
+// hist_counted: keys/hist were already filled for these poses (pfk_resample's fill stage).
 hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, int32_t* hist,
-                     int32_t* next_hist, int32_t* order, double* sorted, PfOrderParams op);
+                     int32_t* next_hist, int32_t* order, double* sorted, PfOrderParams op,
+                     bool hist_counted);
 // K1 on the gather layout (shared grid only). Same beam lists and chunking as pfk_measure_fast.
 hipError_t pfk_measure_swz(hipStream_t st, const double* sorted, int P, const uint8_t* shadow,
                            PfSwz sw, const PfBeamG* bg, const PfBeam* bd, int M, int n_chunks, int bpc,
                            PfGridParams gp, double lmax, const int32_t* order, int2* partial);
 hipError_t pfk_swz_build(hipStream_t st, const uint8_t* lin, uint8_t* shadow, PfSwz sw);
 // bmin: int32 [ceil(P/256)], the smallest sum_match of each 256-particle block
+// zero_a / zero_b: n_zero int32 each set to zero (the ordering's counters), n_zero may be 0
 hipError_t pfk_reduce_scores(hipStream_t st, const int2* partial, int n_chunks, int P, int2* scores,
-                             int32_t* bmin);
+                             int32_t* bmin, int32_t* zero_a, int32_t* zero_b, int n_zero);
 hipError_t pfk_voxel_indices(hipStream_t st, const double* pose, int P, int i, const PfBeam* beams,
                              int M, PfGridParams gp, int32_t* flat_out);
 
@@ -104,13 +121,16 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
 // weights / pose rows / map slabs, arg-max. counters: unsigned long long [3] = {no-hit draws,
 // ambiguous draws, no-hit draws after the re-search}. host_out: device-visible pinned host
 // memory, unsigned long long [4], receives {counters[0..2], best} from the last kernel.
+// order_hist/order_keys (may be null): the one-GPU fill stage also counts K1's lane-order keys of
+// the poses it leaves behind (pfk_order's first stage, saved for the next pf_measure).
 hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int Pg, int P,
                         int offset, double bound, double* w, float* logw, double* pose,
                         const double* pose_gathered, uint8_t* maps, unsigned long long map_stride,
                         unsigned long long map_bytes, int32_t* draw, int32_t* first,
                         int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
                         unsigned long long* counters, PfResampleScratch sc,
-                        unsigned long long* host_out);
+                        unsigned long long* host_out, int32_t* order_hist, int32_t* order_keys,
+                        PfOrderParams op);
 
 // K5: S3P:628-704. rot9: row-major ZYX matrix from the host libm. wpts: double [M][3] scratch.
 struct PfUpdateParams {

@@ -461,9 +461,13 @@ __global__ __launch_bounds__(256) void k_swz_build(const uint8_t* __restrict__ l
 __global__ __launch_bounds__(256) void k_reduce_scores(const int2* __restrict__ partial,
                                                        int n_chunks, int P,
                                                        int2* __restrict__ scores,
-                                                       int32_t* __restrict__ bmin) {
+                                                       int32_t* __restrict__ bmin,
+                                                       int32_t* __restrict__ zero_a,
+                                                       int32_t* __restrict__ zero_b, int n_zero) {
     __shared__ int sh[4];
     const int p = blockIdx.x * 256 + threadIdx.x;
+    // the ordering's 4096-bucket counters are consumed by now (it ran before K1): leave them zero
+    for (int k = p; k < n_zero; k += gridDim.x * 256) { zero_a[k] = 0; zero_b[k] = 0; }
     int sx = 0, sy = 0;
     if (p < P) {
 #pragma unroll 8
@@ -570,17 +574,6 @@ hipError_t pfk_swz_build(hipStream_t st, const uint8_t* lin, uint8_t* shadow, Pf
 // particles share a wave; every per-particle result is independent of it, so the arbitrary
 // order inside a bucket (atomic arrival order) cannot change any output.
 // ------------------------------------------------------------------------------------------
-__device__ inline int spread3(int v) {       // 5 bits -> every third bit
-    return (v & 1) | ((v & 2) << 2) | ((v & 4) << 4) | ((v & 8) << 6) | ((v & 16) << 8);
-}
-__device__ inline int order_key(const double* __restrict__ pose, int P, int i, PfOrderParams op) {
-    const int a = (int)floor(pose[3 * (size_t)P + i] * op.qa);
-    const int x = (int)floor(pose[6 * (size_t)P + i] * op.qx);
-    const int y = (int)floor(pose[7 * (size_t)P + i] * op.qy);
-    if (op.mode == 0) return ((a & 63) << 9) | ((x & 15) << 5) | (y & 31);
-    const int m = (1 << op.bits) - 1;                                          // Morton
-    return (spread3(a & m) << 2) | (spread3(x & m) << 1) | spread3(y & m);
-}
 __global__ __launch_bounds__(256) void k_order_hist(const double* __restrict__ pose, int P,
                                                     int32_t* __restrict__ keys, int32_t* hist,
                                                     PfOrderParams op) {
@@ -638,22 +631,76 @@ __global__ __launch_bounds__(256) void k_order_scatter(const int32_t* __restrict
 #pragma unroll
     for (int k = 0; k < 5; ++k) sorted[(size_t)k * P + r] = pose[(size_t)(4 + k) * P + i];
 }
+// The 4096-bucket form of the last two stages in one launch: every workgroup scans the whole
+// histogram in LDS itself (16 KB, well under a launch boundary's cost), the position inside a
+// bucket comes from a second counter array `cursor`. hist and cursor are zeroed by
+// k_reduce_scores, which every pf_measure runs after K1.
+__global__ __launch_bounds__(256) void k_order_scatter_s(const int32_t* __restrict__ keys, int P,
+                                                         const int32_t* __restrict__ hist,
+                                                         int32_t* cursor, int32_t* __restrict__ order,
+                                                         const double* __restrict__ pose,
+                                                         double* __restrict__ sorted) {
+    __shared__ int off[4096];
+    __shared__ int tot[4];
+    const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6;
+    int4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ((const int4*)hist)[lt * 4 + k];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) tot[wv] = inc;
+    __syncthreads();
+    int run = inc - sum;
+    for (int k = 0; k < wv; ++k) run += tot[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int4 o;
+        o.x = run; run += v[k].x;
+        o.y = run; run += v[k].y;
+        o.z = run; run += v[k].z;
+        o.w = run; run += v[k].w;
+        ((int4*)off)[lt * 4 + k] = o;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + lt;
+    if (i >= P) return;
+    const int key = keys[i];
+    const int r = off[key] + atomicAdd(&cursor[key], 1);
+    order[r] = i;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sorted[(size_t)k * P + r] = pose[(size_t)(4 + k) * P + i];
+}
+// hist_counted: hist/keys already hold this pose set's counts and keys (K4's fill stage made
+// them while it wrote the poses). 4096-bucket keys: hist = counts, next_hist = cursor, both left
+// for k_reduce_scores to zero; otherwise the three-launch form with alternating buffers.
 hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, int32_t* hist,
-                     int32_t* next_hist, int32_t* order, double* sorted, PfOrderParams op) {
-    hipLaunchKernelGGL(k_order_hist, dim3((P + 255) / 256), dim3(256), 0, st, pose, P, keys, hist, op);
-    if (op.mode != 0 && op.bits == 4)
-        hipLaunchKernelGGL(k_order_scan<4>, dim3(1), dim3(1024), 0, st, hist, next_hist);
-    else
-        hipLaunchKernelGGL(k_order_scan<32>, dim3(1), dim3(1024), 0, st, hist, next_hist);
-    hipLaunchKernelGGL(k_order_scatter, dim3((P + 255) / 256), dim3(256), 0, st, keys, P, hist, order,
-                       pose, sorted);
+                     int32_t* next_hist, int32_t* order, double* sorted, PfOrderParams op,
+                     bool hist_counted) {
+    const dim3 grid((P + 255) / 256);
+    if (!hist_counted)
+        hipLaunchKernelGGL(k_order_hist, grid, dim3(256), 0, st, pose, P, keys, hist, op);
+    if (op.mode != 0 && op.bits == 4) {
+        hipLaunchKernelGGL(k_order_scatter_s, grid, dim3(256), 0, st, keys, P, hist, next_hist, order,
+                           pose, sorted);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_order_scan<32>, dim3(1), dim3(1024), 0, st, hist, next_hist);
+    hipLaunchKernelGGL(k_order_scatter, grid, dim3(256), 0, st, keys, P, hist, order, pose, sorted);
     return hipGetLastError();
 }
 
 hipError_t pfk_reduce_scores(hipStream_t st, const int2* partial, int n_chunks, int P,
-                             int2* scores, int32_t* bmin) {
+                             int2* scores, int32_t* bmin, int32_t* zero_a, int32_t* zero_b,
+                             int n_zero) {
     hipLaunchKernelGGL(k_reduce_scores, dim3((P + 255) / 256), dim3(256), 0, st, partial,
-                       n_chunks, P, scores, bmin);
+                       n_chunks, P, scores, bmin, zero_a, zero_b, n_zero);
     return hipGetLastError();
 }
 

@@ -626,13 +626,21 @@ __global__ __launch_bounds__(NB) void k_first_c(double* cdf, const double* __res
 template <bool POSE>
 __device__ inline void d4_apply(int vb, int lt, double* sv4, int* si4, int32_t* slot_anc,
                                 const int32_t* dup_anc, int Pg, double* w, float* logw, double* pose,
-                                double* bbest_v, int32_t* bbest_i) {
+                                double* bbest_v, int32_t* bbest_i, int32_t* order_hist = nullptr,
+                                int32_t* order_keys = nullptr, PfOrderParams op = PfOrderParams{}) {
     const int g = vb * NB + lt, lane = lt & 63, wv4 = lt >> 6;
     double v = 0.0;
     int idx = -1;
     if (g < Pg) {
         int a = slot_anc[g];
         if (a < 0) { a = dup_anc[-1 - a]; slot_anc[g] = a; }   // k-th free slot <- k-th duplicate
+        if (POSE && order_hist) {
+            // slot g ends this step with its ancestor's pose: count its key for the next K1's
+            // lane order now (the first stage of pfk_order)
+            const int key = order_key(pose, Pg, a, op);
+            order_keys[g] = key;
+            atomicAdd(&order_hist[key], 1);
+        }
         v = w[a];
         if (a != g) {
             w[g] = v; logw[g] = logw[a];
@@ -664,10 +672,13 @@ template <bool POSE>
 __global__ __launch_bounds__(NB) void k4_apply(int32_t* __restrict__ slot_anc,
                                                const int32_t* __restrict__ dup_anc, int Pg,
                                                double* w, float* logw, double* pose,
-                                               double* bbest_v, int32_t* bbest_i) {
+                                               double* bbest_v, int32_t* bbest_i,
+                                               int32_t* order_hist, int32_t* order_keys,
+                                               PfOrderParams op) {
     __shared__ double sv[NB / WAVE];
     __shared__ int si[NB / WAVE];
-    d4_apply<POSE>(blockIdx.x, threadIdx.x, sv, si, slot_anc, dup_anc, Pg, w, logw, pose, bbest_v, bbest_i);
+    d4_apply<POSE>(blockIdx.x, threadIdx.x, sv, si, slot_anc, dup_anc, Pg, w, logw, pose, bbest_v, bbest_i,
+                   order_hist, order_keys, op);
 }
 // host_out (may be null): pinned host memory the last stage of K4 writes the step's results to
 // ({no-hit draws, ambiguous draws, no-hit draws after the re-search, best}); the stream
@@ -722,7 +733,8 @@ __global__ __launch_bounds__(WG) void k4_mid(double* cdf, const double* __restri
                                              int32_t* draw, int32_t* first, int32_t* dup_anc,
                                              int32_t* slot_anc, int32_t* best,
                                              unsigned long long* counters, PfResampleScratch sc,
-                                             unsigned long long* host_out) {
+                                             unsigned long long* host_out, int32_t* order_hist,
+                                             int32_t* order_keys, PfOrderParams op) {
     __shared__ double tile[TILE];
     __shared__ int sd[WG / WAVE], sf[WG / WAVE];
     __shared__ double sv[WG / WAVE];
@@ -746,7 +758,7 @@ __global__ __launch_bounds__(WG) void k4_mid(double* cdf, const double* __restri
     __syncthreads();
     for (int vb0 = 0; vb0 < nb; vb0 += WG / NB)
         d4_apply<true>(vb0 + grp, lt, sv + 4 * grp, sd + 4 * grp, slot_anc, dup_anc, Pg, w, logw, pose,
-                       sc.bbest_v, sc.bbest_i);
+                       sc.bbest_v, sc.bbest_i, order_hist, order_keys, op);
     __syncthreads();
     d4_argmax(nb, sc.bbest_v, sc.bbest_i, best, tile, (int*)(tile + WG), counters, host_out);
 }
@@ -845,12 +857,14 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
                         unsigned long long map_bytes, int32_t* draw, int32_t* first,
                         int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
                         unsigned long long* counters, PfResampleScratch sc,
-                        unsigned long long* host_out) {
+                        unsigned long long* host_out, int32_t* order_hist, int32_t* order_keys,
+                        PfOrderParams op) {
     const int nb = nblocks(Pg);
     // counters[0..2] and first[] were initialised by the weight kernels of this step
     if (mid_ok(Pg) && P == Pg && !pose_gathered && !(maps && map_stride)) {
         hipLaunchKernelGGL(k4_mid, dim3(1), dim3(WG), 0, st, (double*)cdf, u, Pg, bound, w, logw, pose,
-                           draw, first, dup_anc, slot_anc, best, counters, sc, host_out);
+                           draw, first, dup_anc, slot_anc, best, counters, sc, host_out, order_hist,
+                           order_keys, op);
         return hipGetLastError();
     }
     const bool folded = nb <= WG && !chain_only();
@@ -874,10 +888,10 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
     }
     if (P == Pg && !pose_gathered) {
         hipLaunchKernelGGL(k4_apply<true>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
-                           pose, sc.bbest_v, sc.bbest_i);
+                           pose, sc.bbest_v, sc.bbest_i, order_hist, order_keys, op);
     } else {
         hipLaunchKernelGGL(k4_apply<false>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
-                           pose, sc.bbest_v, sc.bbest_i);
+                           pose, sc.bbest_v, sc.bbest_i, nullptr, nullptr, op);
         hipLaunchKernelGGL(k_apply_pose, dim3(nblocks(P)), dim3(NB), 0, st, slot_anc, P, offset, pose,
                            pose_gathered);
     }

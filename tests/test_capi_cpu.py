@@ -105,6 +105,17 @@ def test_vote_hypothesis_enumeration():
     assert capi.vote_hypothesis(-1, pos, zyx) is None and capi.vote_hypothesis(k, pos, zyx) is None
 
 
+def test_comm_entry_points_fail_loudly_without_a_gpu():
+    """pf_comm_unique_id binds RCCL at run time: without a device (or without librccl) it must
+    return an error with a message, not crash and not hand out an id."""
+    try:
+        uid = capi.comm_unique_id()
+    except RuntimeError as e:
+        assert "pf_comm_unique_id" in str(e)
+    else:
+        assert len(uid) == 128              # a box with a GPU
+
+
 def test_resample_oracle_properties():
     """Size-independent properties of the resampler the GPU tests also use."""
     rng = np.random.default_rng(1)

@@ -48,7 +48,8 @@ extern "C" {
 #define PF_K_WEIGHTS   1
 #define PF_K_RESAMPLE  2
 #define PF_K_UPDATE    3
-#define PF_K_COUNT     4
+#define PF_K_VOTE      4
+#define PF_K_COUNT     5
 
 typedef struct pf_handle pf_handle;
 

@@ -54,6 +54,8 @@ struct pf_handle {
     double lmax_occ = 0;               // max over occupied beams of max(|lx|+|ly|, |lz|)
     int2* partial = nullptr;           // [max_chunks][P]
     int2* scores = nullptr;            // [P]
+    char* vote_scratch = nullptr;      // pf_scan_vote's device scratch, grown on demand
+    size_t vote_cap = 0;
     int32_t* bmin = nullptr;           // [ceil(P/256)] block minima of scores (pfk_reduce_scores)
     int32_t* draw = nullptr;           // [Pg]
     int32_t* first = nullptr;          // [Pg]
@@ -292,7 +294,7 @@ void pf_destroy(pf_handle* h) {
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
-    void* ptrs[] = {h->bmin, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_occ_g,
+    void* ptrs[] = {h->vote_scratch, h->bmin, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_occ_g,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
                     h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -947,13 +949,19 @@ int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const dou
     }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, wait_map_writes(h));
-    // scratch for this call: matrices, translations, rotated points, sums (not a per-frame hot
-    // allocation problem at 625 hypotheses x 500 points; kept simple)
+    // scratch: matrices, translations, rotated points, sums; kept by the handle and grown on demand
     const size_t nb_m = sizeof(double) * mats.size(), nb_t = sizeof(double) * trans.size();
     const size_t nb_r = sizeof(double) * 3 * (size_t)n_yaw * (size_t)(n_points ? n_points : 1);
     const size_t nb_s = sizeof(int32_t) * (size_t)nh;
-    char* dev = nullptr;
-    HIP_TRY(h, hipMalloc((void**)&dev, nb_m + nb_t + nb_r + nb_s + 64));
+    const size_t need = nb_m + nb_t + nb_r + nb_s + 64;
+    if (need > h->vote_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->vote_scratch) (void)hipFree(h->vote_scratch);
+        h->vote_scratch = nullptr; h->vote_cap = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->vote_scratch, need));
+        h->vote_cap = need;
+    }
+    char* dev = h->vote_scratch;
     double* d_m = (double*)dev; double* d_t = (double*)(dev + nb_m);
     double* d_r = (double*)(dev + nb_m + nb_t); int32_t* d_s = (int32_t*)(dev + nb_m + nb_t + nb_r);
     std::vector<int32_t> sums((size_t)nh);
@@ -961,12 +969,13 @@ int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const dou
     if (e == hipSuccess) e = hipMemcpyAsync(d_t, trans.data(), nb_t, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess && n_points)
         e = hipMemcpyAsync(h->points, points, sizeof(double) * 3 * (size_t)n_points, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess)
+    if (e == hipSuccess) {
+        Timed t(h, PF_K_VOTE);
         e = pfk_scan_vote(h->stream, h->maps, h->points, (int)n_points, d_m, n_yaw, d_t, per, 1 / res,
                           h->cfg.grid_y, h->cfg.grid_z, h->elements, d_r, d_s);
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(sums.data(), d_s, nb_s, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(dev);
     if (e != hipSuccess) return fail(h, PF_ERR_HIP, "pf_scan_vote: %s", hipGetErrorString(e));
     int64_t best = -1; int32_t best_sum = 0;                      // S3P:326, 365
     for (int k = 0; k < nh; ++k)

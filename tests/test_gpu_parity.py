@@ -571,6 +571,58 @@ def test_sharded_backend_on_rccl_single_rank():
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_sharded_handles_at_nonzero_offsets_equal_one_gpu(world):
+    """Every rank's kernels of a `world`-rank job, run one after the other on this one GPU: the
+    gathered scores and pose blocks are assembled by hand from a one-GPU run of the same
+    particles and handed to pf_weights / pf_resample as a collective would (particle_offset > 0,
+    ancestors in other ranks' blocks). Each shard must end with its slice of the one-GPU result."""
+    import torch
+    Pg, M, dims = 5000, 600, (96, 96, 64)
+    P = Pg // world
+    sc = synth.scene(dims, Pg, M, seed=41)
+    rng = np.random.default_rng(41)
+    w0 = rng.random(Pg) + 0.01; w0 /= w0.sum()
+    u = capi.draw_uniform(9, Pg)
+    full = capi.Handle(_shared_cfg(Pg, dims, order_mode=capi.PF_ORDER_FAST))
+    try:
+        full.write_map(0, sc["grid"]); full.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+        full.set_weights(w0); full.set_beams(*sc["beams"]); full.measure(0)
+        fs, fc = full.get_scores()
+        full.synchronize()
+        pose_full = full.poses_tensor().clone()                         # [9, Pg]
+        full.weights()
+        fw, flw = full.get_weights()
+        fslots, fbest, fnohit, famb = full.resample(u)
+        fw2, flw2 = full.get_weights()
+        fposes = np.stack(full.get_poses())
+    finally:
+        full.close()
+    scores_all = torch.from_numpy(np.stack([fs, fc], 1).astype(np.int32)).cuda().contiguous()
+    poses_all = torch.cat([pose_full[:, r * P:(r + 1) * P].contiguous().reshape(-1) for r in range(world)]).contiguous()
+    torch.cuda.synchronize()
+    for r in range(world):
+        lo = r * P
+        h = capi.Handle(_shared_cfg(P, dims, order_mode=capi.PF_ORDER_FAST, n_particles_global=Pg,
+                                    particle_offset=lo))
+        try:
+            h.write_map(0, sc["grid"])
+            h.predict(sc["x"][lo:lo + P], sc["y"][lo:lo + P], sc["z"][lo:lo + P], sc["yaw"][lo:lo + P])
+            h.set_weights(w0); h.set_beams(*sc["beams"]); h.measure(0)
+            s, c = h.get_scores()
+            assert np.array_equal(s, fs[lo:lo + P]) and np.array_equal(c, fc[lo:lo + P])
+            h.weights(scores_all.data_ptr())
+            w, lw = h.get_weights()
+            assert np.array_equal(w, fw) and np.array_equal(lw, flw)      # same bits on every rank
+            slots, best, nohit, amb = h.resample(u, poses_all.data_ptr())
+            assert np.array_equal(slots, fslots) and (best, nohit, amb) == (fbest, fnohit, famb)
+            w2, lw2 = h.get_weights()
+            assert np.array_equal(w2, fw2) and np.array_equal(lw2, flw2)
+            assert np.array_equal(np.stack(h.get_poses()), fposes[:, lo:lo + P])
+        finally:
+            h.close()
+
+
 @pytest.mark.parametrize("seed,n_points", [(21, 500), (22, 37), (23, 0)])
 def test_scan_vote_matches_oracle(seed, n_points):
     """S3P:328-376 (625 pose hypotheses x 500 points on the binary localisation grid).

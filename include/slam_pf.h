@@ -183,6 +183,38 @@ int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const dou
 
 /* ---- plumbing ------------------------------------------------------------------------------ */
 void* pf_stream(pf_handle* h);                           /* the hipStream_t the handle works on */
+/* ---- keyframe ring of the localisation grid: S3P:286-289, 305-312, 419-529 -------------------
+ * (the grid pf_scan_vote reads.) On a PF_MAP_SHARED handle holding the binary
+ * localisation grid (S3P:64). The ring keeps the flat indices of the last n_slots keyframe scans
+ * on the device; live slots are painted before a vote, a slot is replaced when the pose moved by
+ * more than move_threshold, and everything shifts by one flat-index offset when the sensor leaves
+ * the middle of the grid. The non-compacted write of S3P:454-455 is kept (an in-bounds point j is
+ * stored at position j of its slot, only the in-bounds count is kept). Deviation: slot contents
+ * and counts start at zero (the reference reads points_scan_map_index uninitialised, S3P:495). */
+typedef struct pf_ring_params {
+    int32_t n_slots;          /* S3P:286: 5 */
+    int32_t slot_capacity;    /* res_h*res_v = 19200 */
+    int32_t life_new;         /* S3P:463: 6 */
+    int32_t reserved;
+    double move_threshold;    /* S3P:428: 0.15 */
+    double recentre_xy;       /* S3P:485: 2 (metres from the grid's middle) */
+    double recentre_z;        /* S3P:486: 1 */
+} pf_ring_params;
+int pf_ring_default_params(pf_ring_params* p);
+/* Allocates the ring (zeroed) and sets pos_update to the grid's middle, first_run = 1 (S3P:296, 415-416). */
+int pf_ring_init(pf_handle* h, const pf_ring_params* p);
+/* S3P:305-312: grid[idx] = 1 for the entries of every live slot. */
+int pf_ring_paint(pf_handle* h);
+/* S3P:419-529, "after sensor fusion". cloud: n_points rows of sensor-frame xyz (cloudpoints);
+ * pos_scan: in/out (the recentring resets it to the grid's middle, S3P:520-524); zyx =
+ * {euler_zyx_scan[0], rot_y, rot_x}. *flags_out: bit 0 a slot was replaced, bit 1 recentred. */
+int pf_ring_update(pf_handle* h, const double* cloud, int64_t n_points, double pos_scan[3],
+                   const double zyx[3], int32_t* flags_out);
+/* Test/debug read-out: counts[n_slots], lives[n_slots], pos_update[3], euler_update[3], and (when
+ * idx_out != NULL) the n_slots*slot_capacity indices. */
+int pf_ring_state(pf_handle* h, int32_t* counts, int32_t* lives, double pos_update[3],
+                  double euler_update[3], int32_t* idx_out);
+
 /* ---- multi-GPU: the exchange step inside the library ----------------------------
  * No counterpart in the reference (it is one process on one CPU thread, S3P:1107). One process per
  * GPU, one sharded handle per process. Rank 0 calls pf_comm_unique_id (128 bytes) and hands the id

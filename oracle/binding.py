@@ -160,3 +160,42 @@ def scan_vote(grid, resolution, points, pos, zyx, n_yaw=5, yaw_k0=-6, yaw_kstep=
                                _p(points), _p(pos), _p(zyx), n_yaw, yaw_k0, yaw_kstep, n_t,
                                C.c_double(length), _p(sums))
     return sums, best
+
+
+class Ring(C.Structure):
+    _fields_ = [("gx", C.c_int32), ("gy", C.c_int32), ("gz", C.c_int32), ("resolution", C.c_double),
+                ("n_slots", C.c_int32), ("cap", C.c_int32),
+                ("idx", C.POINTER(C.c_int32)), ("count", C.POINTER(C.c_int32)), ("life", C.POINTER(C.c_int32)),
+                ("pos_update", C.c_double * 3), ("euler_update", C.c_double * 3), ("first_run", C.c_int32),
+                ("move_threshold", C.c_double), ("recentre_xy", C.c_double), ("recentre_z", C.c_double),
+                ("life_new", C.c_int32)]
+
+
+class RingState:
+    """The oracle's keyframe ring (pfo_ring) with numpy-owned storage."""
+
+    def __init__(self, dims, resolution=0.05, n_slots=None, cap=None):
+        self.r = Ring()
+        lib().pfo_ring_defaults(C.byref(self.r), dims[0], dims[1], dims[2], C.c_double(resolution))
+        if n_slots is not None:
+            self.r.n_slots = n_slots
+        if cap is not None:
+            self.r.cap = cap
+        self.idx = np.zeros(self.r.n_slots * self.r.cap, np.int32)
+        self.count = np.zeros(self.r.n_slots, np.int32)
+        self.life = np.zeros(self.r.n_slots, np.int32)
+        self.r.idx = self.idx.ctypes.data_as(C.POINTER(C.c_int32))
+        self.r.count = self.count.ctypes.data_as(C.POINTER(C.c_int32))
+        self.r.life = self.life.ctypes.data_as(C.POINTER(C.c_int32))
+
+    def paint(self, grid):
+        assert grid.dtype == np.uint8 and grid.flags.c_contiguous
+        lib().pfo_ring_paint(C.byref(self.r), _p(grid))
+
+    def update(self, grid, cloud, pos_scan, zyx):
+        assert grid.dtype == np.uint8 and grid.flags.c_contiguous
+        cloud = _c(cloud, np.float64).reshape(-1, 3)
+        pos = np.array(pos_scan, np.float64); zyx = _c(zyx, np.float64)
+        lib().pfo_ring_update.restype = C.c_int
+        flags = lib().pfo_ring_update(C.byref(self.r), _p(grid), C.c_int64(len(cloud)), _p(cloud), _p(pos), _p(zyx))
+        return flags, pos

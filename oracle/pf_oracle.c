@@ -291,3 +291,88 @@ int64_t pfo_scan_vote(const uint8_t* grid, int32_t gx, int32_t gy, int32_t gz, d
     free(rot);
     return best;
 }
+
+/* ---- keyframe ring: S3P:305-312, 419-529 -------------------------------------------------- */
+void pfo_ring_defaults(pfo_ring* r, int32_t gx, int32_t gy, int32_t gz, double resolution) {
+    r->gx = gx; r->gy = gy; r->gz = gz; r->resolution = resolution;
+    r->n_slots = 5; r->cap = 19200;
+    r->pos_update[0] = gx * resolution / 2; r->pos_update[1] = gy * resolution / 2;   /* S3P:416 */
+    r->pos_update[2] = gz * resolution / 2;
+    r->euler_update[0] = r->euler_update[1] = r->euler_update[2] = 0;                /* S3P:415 */
+    r->first_run = 1;
+    r->move_threshold = 0.15; r->recentre_xy = 2; r->recentre_z = 1; r->life_new = 6;
+}
+
+void pfo_ring_paint(const pfo_ring* r, uint8_t* grid) {
+    for (int32_t i = 0; i < r->n_slots; i++)                          /* S3P:305-312 */
+        if (r->life[i] > 0)
+            for (int64_t j = (int64_t)i * r->cap; j < (int64_t)i * r->cap + r->count[i]; j++)
+                grid[r->idx[j]] = 1;
+}
+
+int pfo_ring_update(pfo_ring* r, uint8_t* grid, int64_t n, const double* cloud, double pos_scan[3],
+                    const double zyx[3]) {
+    int flags = 0;
+    const double conv = 1 / r->resolution;                            /* S3P:284 */
+    const int64_t elements = (int64_t)r->gx * r->gy * r->gz;
+    const double cx = r->gx * r->resolution / 2, cy = r->gy * r->resolution / 2,
+                 cz = r->gz * r->resolution / 2;                      /* map_size/2 */
+    const double rot_y = zyx[1], rot_x = zyx[2];
+    const double update_value =                                       /* S3P:423-425 */
+        fabs(pos_scan[0] - r->pos_update[0]) + fabs(pos_scan[1] - r->pos_update[1])
+        + fabs(pos_scan[2] - r->pos_update[2]) + 0.5 * fabs(zyx[0] - r->euler_update[0])
+        + 0.5 * fabs(rot_y - r->euler_update[1]) + 0.5 * fabs(rot_x - r->euler_update[2]);
+    if (update_value > r->move_threshold || r->first_run == 1) {      /* S3P:428 */
+        flags |= 1;
+        for (int32_t i = 0; i < r->n_slots; i++) {
+            if (r->life[i] == 1 || r->life[i] <= 0) {                 /* S3P:432 */
+                int32_t* slot = r->idx + (int64_t)i * r->cap;
+                if (r->life[i] != 0)                                  /* S3P:433-437 */
+                    for (int32_t j = 0; j < r->count[i]; j++) grid[slot[j]] = 0;
+                double m[9];
+                pfo_rot_zyx(m, zyx[0], rot_y, rot_x);                 /* S3P:439 */
+                r->count[i] = 0;
+                for (int64_t j = 0; j < n && j < r->cap; j++) {       /* S3P:445-459 */
+                    const double* p = cloud + 3 * j;
+                    const double wx = (m[0] * p[0] + m[1] * p[1] + m[2] * p[2]) + pos_scan[0];
+                    const double wy = (m[3] * p[0] + m[4] * p[1] + m[5] * p[2]) + pos_scan[1];
+                    const double wz = (m[6] * p[0] + m[7] * p[1] + m[8] * p[2]) + pos_scan[2];
+                    const int64_t f = flat_int(r->gy, r->gz, wx * conv, wy * conv, wz * conv, elements);
+                    if (f < 0) continue;
+                    slot[j] = (int32_t)f;                             /* S3P:454: at j, not at count */
+                    r->count[i] += 1;
+                }
+                r->life[i] = r->life_new;                             /* S3P:463 */
+                break;
+            }
+        }
+        for (int32_t i = 0; i < r->n_slots; i++) r->life[i] += -1;    /* S3P:470-472 */
+        r->first_run = 0;
+        r->pos_update[0] = pos_scan[0]; r->pos_update[1] = pos_scan[1]; r->pos_update[2] = pos_scan[2];
+        r->euler_update[0] = zyx[0]; r->euler_update[1] = rot_y; r->euler_update[2] = rot_x;
+    }
+    if (fabs(pos_scan[0] - cx) > r->recentre_xy || fabs(pos_scan[1] - cy) > r->recentre_xy ||
+        fabs(pos_scan[2] - cz) > r->recentre_z) {                     /* S3P:485-486 */
+        flags |= 2;
+        int bad = 0;
+        const int64_t ox = to_i32(round((cx - pos_scan[0]) * conv), &bad);   /* S3P:489-491 */
+        const int64_t oy = to_i32(round((cy - pos_scan[1]) * conv), &bad);
+        const int64_t oz = to_i32(round((cz - pos_scan[2]) * conv), &bad);
+        const int64_t corr = ox * r->gy * r->gz + oy * r->gz + oz;    /* S3P:494 */
+        for (int32_t i = 0; i < r->n_slots; i++) {
+            int32_t* slot = r->idx + (int64_t)i * r->cap;
+            for (int32_t j = 0; j < r->count[i]; j++) grid[slot[j]] = 0;      /* S3P:498-500 */
+            int32_t off = 0;
+            for (int32_t j = 0; j < r->count[i]; j++) {               /* S3P:502-515 */
+                const int64_t ni = (int64_t)slot[j] + corr;
+                if (bad || ni < 0 || ni >= elements) off += 1;
+                else slot[j - off] = (int32_t)ni;
+            }
+            r->count[i] += -off;                                      /* S3P:516 */
+        }
+        r->pos_update[0] += cx - pos_scan[0]; pos_scan[0] = cx;       /* S3P:519-524 */
+        r->pos_update[1] += cy - pos_scan[1]; pos_scan[1] = cy;
+        r->pos_update[2] += cz - pos_scan[2]; pos_scan[2] = cz;
+    }
+    return flags;
+}

@@ -8,7 +8,7 @@
  *     own particle_map() (S3P:827-962) and resample() (S3P:757-821), compiled from the
  *     reference's text by oracle/build_ref.sh and run in the build container; vectors in
  *     tests/golden/ (generator: oracle/make_golden.py).
- *   pfo_update_map / pfo_scan_vote — PARITY UNPINNED: build_local_map (S3P:621-710) and
+ *   pfo_update_map / pfo_scan_vote / pfo_ring_* — PARITY UNPINNED: build_local_map (S3P:621-710) and
  *     scan_localization (S3P:300-410) are members of a class whose other members are ROS
  *     types, ROS is absent from this image and no stand-in may be written, and the reference
  *     holds no test or golden vector. They restate the cited lines as read.
@@ -97,6 +97,39 @@ typedef struct pfo_update_cfg {
 void pfo_update_map(const pfo_update_cfg* c, void* grid,
                     const double pos[3], const double zyx[3],
                     int64_t M, const double* points, int64_t R, const int32_t* ray_idx);
+
+/* ---- keyframe ring of the localisation grid: S3P:286-289, 305-312, 419-529 --
+ * PARITY UNPINNED (members of class Slam, like pfo_scan_vote). The ring keeps, for n_slots past
+ * scans, the flat indices their points fell on; live slots are painted into the binary grid
+ * before every vote, a slot is replaced when the pose has moved, and everything is shifted by a
+ * flat-index offset when the sensor leaves the middle of the grid.
+ * Kept on purpose: the non-compacted write of S3P:454-455 (an in-bounds point j of a new scan is
+ * stored at position j of its slot while only the in-bounds COUNT is kept, so later passes over
+ * the first `count` entries see holes with older contents and miss the tail).
+ * Deviations (defined behaviour for the reference's UB): idx[] and count[] start at zero (the
+ * reference leaves points_scan_map_index uninitialised and S3P:495-517 reads it for slots never
+ * filled); rounded coordinates outside int32 are out of bounds. */
+typedef struct pfo_ring {
+    int32_t gx, gy, gz;
+    double resolution;
+    int32_t n_slots, cap;          /* S3P:286: 5; res_h*res_v = 19200 */
+    int32_t* idx;                  /* [n_slots*cap] points_scan_map, caller-allocated, zeroed */
+    int32_t* count;                /* [n_slots] points_scan_map_index, zeroed */
+    int32_t* life;                 /* [n_slots] points_scan_map_life, zeroed (S3P:289) */
+    double pos_update[3];          /* S3P:416: the grid's centre in metres at start */
+    double euler_update[3];        /* S3P:415 */
+    int32_t first_run;             /* S3P:296: 1 */
+    double move_threshold;         /* S3P:428: 0.15 */
+    double recentre_xy, recentre_z;/* S3P:485-486: 2, 1 */
+    int32_t life_new;              /* S3P:463: 6 */
+} pfo_ring;
+void pfo_ring_defaults(pfo_ring* r, int32_t gx, int32_t gy, int32_t gz, double resolution);
+/* S3P:305-312 */
+void pfo_ring_paint(const pfo_ring* r, uint8_t* grid);
+/* S3P:419-529. cloud: n sensor-frame points; pos_scan (in/out, S3P:520-524) and zyx =
+ * {euler_zyx_scan[0], rot_y, rot_x}. Returns bit 0: a slot was replaced, bit 1: recentred. */
+int pfo_ring_update(pfo_ring* r, uint8_t* grid, int64_t n, const double* cloud, double pos_scan[3],
+                    const double zyx[3]);
 
 /* S3P:328-376: pose-lattice vote on a binary uint8 grid. Yaw hypothesis r is
  * zyx[0] + (yaw_k0 + yaw_kstep*r)*pi/180 (S3P:329: k0 = -6, kstep = 3, n_yaw = 5); translation

@@ -25,7 +25,8 @@ SYMBOLS = (
     "pf_poses_device pf_set_scan pf_update_map pf_scan_vote pf_write_local_map pf_read_local_map "
     "pf_reset_local_map pf_stream pf_set_stream pf_synchronize pf_profile pf_kernel_time "
     "pfh_snapshot_beams pfh_predict pfh_draw_noise pfh_draw_uniform pfh_add_points_policy "
-    "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init").split()
+    "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init "
+    "pf_ring_default_params pf_ring_init pf_ring_paint pf_ring_update pf_ring_state").split()
 
 
 class Config(C.Structure):
@@ -38,6 +39,12 @@ class Config(C.Structure):
                 ("occ_threshold", C.c_int32), ("map_lo", C.c_int32), ("map_hi", C.c_int32),
                 ("map_prior", C.c_int32), ("order_mode", C.c_int32),
                 ("resolution", C.c_double)]
+
+
+class RingParams(C.Structure):
+    _fields_ = [("n_slots", C.c_int32), ("slot_capacity", C.c_int32), ("life_new", C.c_int32),
+                ("reserved", C.c_int32), ("move_threshold", C.c_double), ("recentre_xy", C.c_double),
+                ("recentre_z", C.c_double)]
 
 
 class UpdateParams(C.Structure):
@@ -254,6 +261,37 @@ class Handle:
                                     n_yaw, yaw_k0, yaw_kstep, n_t, C.c_double(length), _p(sums),
                                     C.byref(best)), "pf_scan_vote")
         return sums, best.value
+
+    # --- keyframe ring of the localisation grid (S3P:305-312, 419-529) ---
+    def ring_init(self, **kw):
+        p = RingParams()
+        lib().pf_ring_default_params(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        self._ck(lib().pf_ring_init(self._h, C.byref(p)), "pf_ring_init")
+        self._ring = p
+
+    def ring_paint(self):
+        self._ck(lib().pf_ring_paint(self._h), "pf_ring_paint")
+
+    def ring_update(self, cloud, pos_scan, zyx):
+        """Returns (flags, pos_scan after the call)."""
+        cloud = _c(cloud, np.float64).reshape(-1, 3)
+        pos = np.array(pos_scan, np.float64); zyx = _c(zyx, np.float64)
+        flags = C.c_int32(0)
+        self._ck(lib().pf_ring_update(self._h, _p(cloud), C.c_int64(len(cloud)), _p(pos), _p(zyx),
+                                      C.byref(flags)), "pf_ring_update")
+        return flags.value, pos
+
+    def ring_state(self, with_idx=False):
+        n, cap = self._ring.n_slots, self._ring.slot_capacity
+        counts = np.empty(n, np.int32); lives = np.empty(n, np.int32)
+        pu = np.empty(3, np.float64); eu = np.empty(3, np.float64)
+        idx = np.empty(n * cap, np.int32) if with_idx else None
+        self._ck(lib().pf_ring_state(self._h, _p(counts), _p(lives), _p(pu), _p(eu), _p(idx)), "pf_ring_state")
+        return counts, lives, pu, eu, (idx.reshape(n, cap) if with_idx else None)
 
     def write_local_map(self, src):
         src = _c(src, np.int8).reshape(-1)

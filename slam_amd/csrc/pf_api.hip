@@ -54,6 +54,14 @@ struct pf_handle {
     double lmax_occ = 0;               // max over occupied beams of max(|lx|+|ly|, |lz|)
     int2* partial = nullptr;           // [max_chunks][P]
     int2* scores = nullptr;            // [P]
+    // keyframe ring (pf_ring_*): indices on the device, bookkeeping here
+    pf_ring_params ring{};
+    int32_t* ring_idx = nullptr;       // [n_slots][slot_capacity]
+    int32_t* ring_cnt = nullptr;       // device scalar for kernel-side counts
+    double* ring_pts = nullptr;        // [slot_capacity][3] the scan being indexed
+    std::vector<int32_t> ring_count, ring_life;
+    double ring_pos_update[3] = {0, 0, 0}, ring_euler_update[3] = {0, 0, 0};
+    int ring_first_run = 1;
     char* vote_scratch = nullptr;      // pf_scan_vote's device scratch, grown on demand
     size_t vote_cap = 0;
     int32_t* bmin = nullptr;           // [ceil(P/256)] block minima of scores (pfk_reduce_scores)
@@ -294,7 +302,7 @@ void pf_destroy(pf_handle* h) {
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
-    void* ptrs[] = {h->vote_scratch, h->bmin, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_occ_g,
+    void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_occ_g,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
                     h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1006,6 +1014,165 @@ int pf_reset_local_map(pf_handle* h) {
     NEED(h, h->local, "no local map");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemsetAsync(h->local, 0, (size_t)h->local_elements, h->stream));
+    return PF_OK;
+}
+
+int pf_ring_default_params(pf_ring_params* p) {
+    if (!p) return PF_ERR_ARG;
+    p->n_slots = 5; p->slot_capacity = 19200; p->life_new = 6; p->reserved = 0;   // S3P:286, 463
+    p->move_threshold = 0.15; p->recentre_xy = 2.0; p->recentre_z = 1.0;          // S3P:428, 485-486
+    return PF_OK;
+}
+
+int pf_ring_init(pf_handle* h, const pf_ring_params* p) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, p, "null params");
+    NEED(h, h->cfg.map_mode == PF_MAP_SHARED, "needs a PF_MAP_SHARED handle (the localisation grid)");
+    NEED(h, p->n_slots >= 1 && p->n_slots <= 64 && p->slot_capacity >= 1 && p->slot_capacity <= (1 << 24),
+         "n_slots in 1..64, slot_capacity in 1..2^24");
+    NEED(h, h->elements < (1ll << 31), "grid too large for int32 indices");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->ring_idx) { (void)hipFree(h->ring_idx); h->ring_idx = nullptr; }
+    if (h->ring_pts) { (void)hipFree(h->ring_pts); h->ring_pts = nullptr; }
+    HIP_TRY(h, dalloc(&h->ring_pts, 3 * (size_t)p->slot_capacity));
+    if (!h->ring_cnt) HIP_TRY(h, dalloc(&h->ring_cnt, 1));
+    const size_t n = (size_t)p->n_slots * (size_t)p->slot_capacity;
+    HIP_TRY(h, dalloc(&h->ring_idx, n));
+    HIP_TRY(h, hipMemsetAsync(h->ring_idx, 0, sizeof(int32_t) * n, h->stream));
+    h->ring = *p;
+    h->ring_count.assign((size_t)p->n_slots, 0);
+    h->ring_life.assign((size_t)p->n_slots, 0);                                   // S3P:289
+    const double res = h->cfg.resolution;
+    h->ring_pos_update[0] = h->cfg.grid_x * res / 2;                              // S3P:416
+    h->ring_pos_update[1] = h->cfg.grid_y * res / 2;
+    h->ring_pos_update[2] = h->cfg.grid_z * res / 2;
+    h->ring_euler_update[0] = h->ring_euler_update[1] = h->ring_euler_update[2] = 0;   // S3P:415
+    h->ring_first_run = 1;                                                        // S3P:296
+    return PF_OK;
+}
+
+int pf_ring_paint(pf_handle* h) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, h->ring_idx, "pf_ring_init first");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, wait_map_writes(h));
+    for (int i = 0; i < h->ring.n_slots; ++i)                                     // S3P:305-312
+        if (h->ring_life[(size_t)i] > 0)
+            HIP_TRY(h, pfk_ring_set(h->stream, h->maps, h->ring_idx + (size_t)i * h->ring.slot_capacity,
+                                    h->ring_count[(size_t)i], 1));
+    h->shadow_dirty = true;
+    return PF_OK;
+}
+
+int pf_ring_update(pf_handle* h, const double* cloud, int64_t n_points, double pos_scan[3],
+                   const double zyx[3], int32_t* flags_out) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, h->ring_idx, "pf_ring_init first");
+    NEED(h, pos_scan && zyx && (n_points == 0 || cloud), "null argument");
+    NEED(h, n_points >= 0 && n_points <= h->ring.slot_capacity, "n_points beyond slot_capacity");
+    for (int k = 0; k < 3; ++k)
+        NEED(h, isfinite(pos_scan[k]) && fabs(pos_scan[k]) < 1e6 && isfinite(zyx[k]), "pose not finite");
+    for (int64_t i = 0; i < 3 * n_points; ++i)
+        if (!(fabs(cloud[i]) < 1.0e6)) return fail(h, PF_ERR_ARG, "pf_ring_update: point %lld not finite/too far", (long long)(i / 3));
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, wait_map_writes(h));
+    const pf_ring_params& rp = h->ring;
+    const double res = h->cfg.resolution, conv = 1 / res;                         // S3P:284
+    const double cx = h->cfg.grid_x * res / 2, cy = h->cfg.grid_y * res / 2, cz = h->cfg.grid_z * res / 2;
+    const double rot_y = zyx[1], rot_x = zyx[2];
+    int flags = 0;
+    const double update_value =                                                   // S3P:423-425
+        fabs(pos_scan[0] - h->ring_pos_update[0]) + fabs(pos_scan[1] - h->ring_pos_update[1])
+        + fabs(pos_scan[2] - h->ring_pos_update[2]) + 0.5 * fabs(zyx[0] - h->ring_euler_update[0])
+        + 0.5 * fabs(rot_y - h->ring_euler_update[1]) + 0.5 * fabs(rot_x - h->ring_euler_update[2]);
+    if (update_value > rp.move_threshold || h->ring_first_run == 1) {             // S3P:428
+        flags |= 1;
+        for (int i = 0; i < rp.n_slots; ++i) {
+            int32_t& life = h->ring_life[(size_t)i];
+            if (life == 1 || life <= 0) {                                         // S3P:432
+                int32_t* slot = h->ring_idx + (size_t)i * rp.slot_capacity;
+                if (life != 0)                                                    // S3P:433-437
+                    HIP_TRY(h, pfk_ring_set(h->stream, h->maps, slot, h->ring_count[(size_t)i], 0));
+                PfUpdateParams up{};
+                const double z = zyx[0], y = rot_y, x = rot_x;
+                up.rot[0] = cos(y) * cos(z);                                      // S3P:536-544, host libm
+                up.rot[1] = cos(z) * sin(x) * sin(y) - cos(x) * sin(z);
+                up.rot[2] = sin(x) * sin(z) + cos(x) * cos(z) * sin(y);
+                up.rot[3] = cos(y) * sin(z);
+                up.rot[4] = cos(x) * cos(z) + sin(x) * sin(y) * sin(z);
+                up.rot[5] = cos(x) * sin(y) * sin(z) - cos(z) * sin(x);
+                up.rot[6] = -sin(y);
+                up.rot[7] = cos(y) * sin(x);
+                up.rot[8] = cos(x) * cos(y);
+                up.pos[0] = pos_scan[0]; up.pos[1] = pos_scan[1]; up.pos[2] = pos_scan[2];
+                up.conv = conv; up.elements = h->elements; up.gy = h->cfg.grid_y; up.gz = h->cfg.grid_z;
+                int32_t cnt = 0;
+                if (n_points) {
+                    HIP_TRY(h, hipMemcpyAsync(h->ring_pts, cloud, sizeof(double) * 3 * (size_t)n_points,
+                                              hipMemcpyHostToDevice, h->stream));
+                    HIP_TRY(h, hipMemsetAsync(h->ring_cnt, 0, sizeof(int32_t), h->stream));
+                    HIP_TRY(h, pfk_ring_fill(h->stream, h->ring_pts, (int)n_points, up, slot, h->ring_cnt));
+                    HIP_TRY(h, hipMemcpyAsync(&cnt, h->ring_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                    HIP_TRY(h, hipStreamSynchronize(h->stream));
+                }
+                h->ring_count[(size_t)i] = cnt;                                   // S3P:444-455
+                life = rp.life_new;                                               // S3P:463
+                break;
+            }
+        }
+        for (int i = 0; i < rp.n_slots; ++i) h->ring_life[(size_t)i] += -1;       // S3P:470-472
+        h->ring_first_run = 0;
+        for (int k = 0; k < 3; ++k) h->ring_pos_update[k] = pos_scan[k];          // S3P:475-480
+        h->ring_euler_update[0] = zyx[0]; h->ring_euler_update[1] = rot_y; h->ring_euler_update[2] = rot_x;
+        h->shadow_dirty = true;
+    }
+    if (fabs(pos_scan[0] - cx) > rp.recentre_xy || fabs(pos_scan[1] - cy) > rp.recentre_xy ||
+        fabs(pos_scan[2] - cz) > rp.recentre_z) {                                 // S3P:485-486
+        flags |= 2;
+        const long long ox = (long long)round((cx - pos_scan[0]) * conv);         // S3P:489-491
+        const long long oy = (long long)round((cy - pos_scan[1]) * conv);
+        const long long oz = (long long)round((cz - pos_scan[2]) * conv);
+        const long long corr = ox * h->cfg.grid_y * h->cfg.grid_z + oy * h->cfg.grid_z + oz;   // S3P:494
+        for (int i = 0; i < rp.n_slots; ++i) {
+            int32_t* slot = h->ring_idx + (size_t)i * rp.slot_capacity;
+            const int cnt_old = h->ring_count[(size_t)i];
+            HIP_TRY(h, pfk_ring_set(h->stream, h->maps, slot, cnt_old, 0));       // S3P:498-500
+            int32_t cnt = 0;
+            if (cnt_old > 0) {
+                HIP_TRY(h, pfk_ring_shift(h->stream, slot, cnt_old, corr, h->elements, h->ring_cnt));   // S3P:502-516
+                HIP_TRY(h, hipMemcpyAsync(&cnt, h->ring_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+            }
+            h->ring_count[(size_t)i] = cnt;
+        }
+        h->ring_pos_update[0] += cx - pos_scan[0]; pos_scan[0] = cx;              // S3P:519-524
+        h->ring_pos_update[1] += cy - pos_scan[1]; pos_scan[1] = cy;
+        h->ring_pos_update[2] += cz - pos_scan[2]; pos_scan[2] = cz;
+        h->shadow_dirty = true;
+    }
+    if (flags_out) *flags_out = flags;
+    return PF_OK;
+}
+
+int pf_ring_state(pf_handle* h, int32_t* counts, int32_t* lives, double pos_update[3],
+                  double euler_update[3], int32_t* idx_out) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, h->ring_idx, "pf_ring_init first");
+    for (int i = 0; i < h->ring.n_slots; ++i) {
+        if (counts) counts[i] = h->ring_count[(size_t)i];
+        if (lives) lives[i] = h->ring_life[(size_t)i];
+    }
+    for (int k = 0; k < 3; ++k) {
+        if (pos_update) pos_update[k] = h->ring_pos_update[k];
+        if (euler_update) euler_update[k] = h->ring_euler_update[k];
+    }
+    if (idx_out) {
+        HIP_TRY(h, hipSetDevice(h->cfg.device));
+        HIP_TRY(h, hipMemcpyAsync(idx_out, h->ring_idx, sizeof(int32_t) * (size_t)h->ring.n_slots * h->ring.slot_capacity,
+                                  hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     return PF_OK;
 }
 

@@ -157,3 +157,11 @@ hipError_t pfk_scan_vote(hipStream_t st, const uint8_t* grid, const double* poin
                          const double* mats, int n_yaw, const double* trans, int n_per_yaw,
                          double conv, int gy, int gz, long long elements, double* rot,
                          int32_t* sums);
+
+// Keyframe ring (S3P:305-312, 419-529). slot: int32 [cap] flat indices of one ring slot.
+hipError_t pfk_ring_set(hipStream_t st, uint8_t* grid, const int32_t* slot, int count, int value);
+// *count_out (zero on entry) += in-bounds points; up: rot, pos, conv, gy, gz, elements.
+hipError_t pfk_ring_fill(hipStream_t st, const double* points, int n, PfUpdateParams up, int32_t* slot,
+                         int32_t* count_out);
+hipError_t pfk_ring_shift(hipStream_t st, int32_t* slot, int count, long long corr, long long elements,
+                          int32_t* count_out);

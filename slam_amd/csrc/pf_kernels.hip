@@ -894,3 +894,79 @@ hipError_t pfk_scan_vote(hipStream_t st, const uint8_t* grid, const double* poin
                        n_per_yaw, conv, gy, gz, elements, sums);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------
+// Keyframe ring of the localisation grid: S3P:305-312, 419-529. The ring's
+// flat indices live in HBM (int32 [n_slots][cap]); counts, lives and the move/recentre decisions
+// are host state in pf_api.hip.
+// ------------------------------------------------------------------------------------------
+// S3P:309 / 435 / 499: grid[slot[j]] = value for the first `count` entries (duplicates are fine)
+__global__ __launch_bounds__(256) void k_ring_set(uint8_t* __restrict__ grid,
+                                                  const int32_t* __restrict__ slot, int count,
+                                                  int value) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < count) grid[slot[j]] = (uint8_t)value;
+}
+// S3P:439-459: rotate, translate, index; an in-bounds point j lands at slot[j] (not compacted:
+// the reference's quirk), *count_out += the number of in-bounds points.
+__global__ __launch_bounds__(256) void k_ring_fill(const double* __restrict__ points, int n,
+                                                   PfUpdateParams up, int32_t* __restrict__ slot,
+                                                   int32_t* count_out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    bool in = false;
+    if (j < n) {
+        const double px = points[3 * (size_t)j], py = points[3 * (size_t)j + 1], pz = points[3 * (size_t)j + 2];
+        const double wx = (up.rot[0] * px + up.rot[1] * py + up.rot[2] * pz) + up.pos[0];   // S3P:547-557
+        const double wy = (up.rot[3] * px + up.rot[4] * py + up.rot[5] * pz) + up.pos[1];
+        const double wz = (up.rot[6] * px + up.rot[7] * py + up.rot[8] * pz) + up.pos[2];
+        const long long f = flat_of(wx * up.conv, wy * up.conv, wz * up.conv, up);          // S3P:446-450
+        in = f >= 0;
+        if (in) slot[j] = (int32_t)f;                                                       // S3P:454
+    }
+    const int c = __popcll(__ballot(in));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count_out, c);                              // S3P:455
+}
+// S3P:502-516: add `corr` to the first `count` entries, drop the ones that leave the grid, keep
+// the order (the sequential loop writes entry j to j - dropped_so_far). One workgroup; a tile is
+// read completely before it is written, and writes only go to positions at or below their source.
+__global__ __launch_bounds__(1024) void k_ring_shift(int32_t* slot, int count, long long corr,
+                                                     long long elements, int32_t* count_out) {
+    __shared__ int wtot[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < count; t0 += 1024) {
+        const int j = t0 + tid;
+        long long ni = -1;
+        if (j < count) ni = (long long)slot[j] + corr;
+        const bool keep = j < count && ni >= 0 && ni < elements;
+        const unsigned long long m = __ballot(keep);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wtot[wv] = __popcll(m);
+        __syncthreads();                                   // all reads of this tile are done
+        int off = base_s;
+        for (int k = 0; k < wv; ++k) off += wtot[k];
+        if (keep) slot[off + rank] = (int32_t)ni;
+        __syncthreads();
+        if (tid == 0) { int s = 0; for (int k = 0; k < 16; ++k) s += wtot[k]; base_s += s; }
+        __syncthreads();
+    }
+    if (tid == 0) *count_out = base_s;
+}
+hipError_t pfk_ring_set(hipStream_t st, uint8_t* grid, const int32_t* slot, int count, int value) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ring_set, dim3((count + 255) / 256), dim3(256), 0, st, grid, slot, count, value);
+    return hipGetLastError();
+}
+hipError_t pfk_ring_fill(hipStream_t st, const double* points, int n, PfUpdateParams up, int32_t* slot,
+                         int32_t* count_out) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ring_fill, dim3((n + 255) / 256), dim3(256), 0, st, points, n, up, slot, count_out);
+    return hipGetLastError();
+}
+hipError_t pfk_ring_shift(hipStream_t st, int32_t* slot, int count, long long corr, long long elements,
+                          int32_t* count_out) {
+    hipLaunchKernelGGL(k_ring_shift, dim3(1), dim3(1024), 0, st, slot, count, corr, elements, count_out);
+    return hipGetLastError();
+}

@@ -661,3 +661,69 @@ def test_scan_vote_matches_oracle(seed, n_points):
         assert want.max() > n_points // 4               # the case does vote
     if n_points == 0:
         assert got_best == -1
+
+
+def _ring_frames(dims, n_frames, cap, seed):
+    """A drifting sensor with scans of a room: enough motion for slot replacement every few
+    frames and for the recentring (S3P:485) to trigger, some points outside the grid (holes)."""
+    rng = np.random.default_rng(seed)
+    res = 0.05
+    room = synth.make_room(dims, seed=seed)
+    occ = np.argwhere(room == 100) * res
+    centre = np.array(dims) * res / 2
+    pos = centre + np.array([0.3, -0.2, 0.05])
+    yaw = 0.1
+    frames = []
+    for t in range(n_frames):
+        pos = pos + np.array([0.11, 0.07, 0.012]) + rng.normal(0, 0.01, 3)
+        yaw += 0.03
+        zyx = np.array([yaw, rng.normal(0, 0.01), rng.normal(0, 0.01)])
+        n = int(rng.integers(cap // 2, cap + 1)) if t % 7 else 0
+        wp = occ[rng.integers(0, len(occ), n)] + rng.normal(0, 0.01, (n, 3))
+        if n > 10:
+            wp[::9] += 40.0                                   # far outside the grid
+        cz, sz = np.cos(zyx[0]), np.sin(zyx[0])
+        R = np.array(O.rot_zyx(*zyx)).reshape(3, 3)
+        cloud = (wp - pos) @ R                                 # sensor frame
+        frames.append((cloud, pos.copy(), zyx))
+    return frames
+
+
+def test_keyframe_ring_matches_oracle():
+    """S3P:305-312, 419-529: slot replacement with the non-compacted write,
+    painting, erasing, and the flat-offset recentring. PARITY UNPINNED by the reference (members
+    of class Slam): checked against the restatement, every index of every slot after every
+    frame, then a vote (K6) on the painted grid."""
+    dims = (120, 100, 48)
+    cap = 3000
+    frames = _ring_frames(dims, 45, cap, 7)
+    ring = O.RingState(dims, 0.05, n_slots=5, cap=cap)
+    grid = np.zeros(dims, np.uint8)
+    h = capi.Handle(_shared_cfg(1, dims))
+    try:
+        h.fill_maps(0)
+        h.ring_init(slot_capacity=cap)
+        seen = 0
+        for t, (cloud, pos, zyx) in enumerate(frames):
+            ring.paint(grid); h.ring_paint()
+            assert np.array_equal(h.read_map(0).reshape(dims), grid), t
+            of, opos = ring.update(grid, cloud, pos, zyx)
+            gf, gpos = h.ring_update(cloud, pos, zyx)
+            assert gf == of and np.array_equal(gpos, opos), t
+            counts, lives, pu, eu, idx = h.ring_state(with_idx=True)
+            assert np.array_equal(counts, ring.count) and np.array_equal(lives, ring.life), t
+            assert np.array_equal(pu, np.array(ring.r.pos_update)) and np.array_equal(eu, np.array(ring.r.euler_update)), t
+            assert np.array_equal(idx.reshape(-1), ring.idx), t
+            assert np.array_equal(h.read_map(0).reshape(dims), grid), t
+            seen |= of
+            if of & 2:                                         # the caller carries the reset pose on
+                for k in range(t + 1, len(frames)):
+                    frames[k] = (frames[k][0], frames[k][1] - (pos - opos), frames[k][2])
+        assert seen == 3                                       # both branches ran
+        ring.paint(grid); h.ring_paint()
+        cloud, pos, zyx = frames[-1]
+        want, wbest = O.scan_vote(grid, 0.05, cloud[:500], pos, zyx)
+        got, gbest = h.scan_vote(cloud[:500], pos, zyx)
+        assert np.array_equal(got, want) and gbest == wbest and want.max() > 0
+    finally:
+        h.close()

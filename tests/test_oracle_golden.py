@@ -163,3 +163,33 @@ def test_200_step_run_matches_reference(golden_dir):
     assert np.array_equal(np.stack([st.x, st.y, st.z, st.yaw, be.w], 1), g["state_final"])
     crc = np.array([zlib.crc32(be.maps[i].tobytes()) for i in range(P)], np.uint32)
     assert np.array_equal(crc, g["map_crc"])
+
+
+def test_ring_restatement_invariants():
+    """pfo_ring_* (S3P:305-312, 419-529; parity unpinned): the life cycle of S3P:432-472 and the
+    non-compacted write of S3P:454-455, on a case small enough to follow by hand."""
+    dims = (20, 20, 10)
+    ring = O.RingState(dims, 0.05, n_slots=3, cap=8)
+    grid = np.zeros(dims, np.uint8)
+    centre = np.array(dims) * 0.05 / 2
+    zyx = np.zeros(3)
+    # points 1 and 3 leave the grid: in-bounds points stay at positions 0, 2, 4, count = 3
+    cloud = np.array([[0.1, 0, 0], [50, 0, 0], [0, 0.1, 0], [0, -50, 0], [0, 0, 0.1]])
+    flags, pos = ring.update(grid, cloud, centre, zyx)
+    assert flags == 1 and ring.count[0] == 3 and ring.life.tolist() == [5, -1, -1]
+    stored = ring.idx[:8].copy()
+    assert stored[1] == 0 and stored[3] == 0 and stored[0] > 0 and stored[2] > 0 and stored[4] > 0
+    ring.paint(grid)
+    # the first `count` entries are painted: positions 0, 1 (a hole holding index 0) and 2 — not 4
+    assert grid.reshape(-1)[stored[0]] == 1 and grid.reshape(-1)[0] == 1 and grid.reshape(-1)[stored[2]] == 1
+    assert grid.reshape(-1)[stored[4]] == 0
+    # no motion: nothing changes
+    flags, _ = ring.update(grid, cloud, centre, zyx)
+    assert flags == 0 and ring.life.tolist() == [5, -1, -1]
+    # far from the middle: recentred, pose reset to the middle, indices shifted by one offset
+    far = centre + np.array([0.3, 0, 0])
+    ring.r.recentre_xy = 0.2
+    flags, pos = ring.update(grid, cloud, far, zyx)
+    assert flags == 3 and np.array_equal(pos, centre)
+    assert not grid.any()                                   # S3P:498-500 erased what was painted
+    assert ring.life.tolist() == [4, 5, -2]                 # a second slot was taken (6), then all aged

@@ -215,6 +215,26 @@ int pf_ring_update(pf_handle* h, const double* cloud, int64_t n_points, double p
 int pf_ring_state(pf_handle* h, int32_t* counts, int32_t* lives, double pos_update[3],
                   double euler_update[3], int32_t* idx_out);
 
+/* ---- depth front-end: S3P:562-612 with the tables S3P:116-124, 155-162 -----
+ * Replaces callback()'s pooling and projection. image: host pointer to height rows of width
+ * little-endian uint16 depths in millimetres (sensor_msgs/Image::data, S3P:587); pooled pool x pool
+ * with the integer mean that ignores zeros (S3P:580-594); focal = the pooled focal length
+ * (S3P:124: 385.0/4.0); millimetre products truncated toward zero (S3P:567-568), metres
+ * (S3P:603-605); pixels whose pooled depth is 0 dropped, row-major order kept. cloud_out: host
+ * double [capacity][3], capacity >= (width/pool)*(height/pool); *n_out = points written
+ * (the reference's cloudpoints.size()). */
+int pf_depth_to_cloud(pf_handle* h, const uint8_t* image, int32_t width, int32_t height, int32_t pool,
+                      double focal, double* cloud_out, int64_t capacity, int64_t* n_out);
+
+/* ---- map read-out for publishing: S3P:1031-1051 with reverse_index_conv_p S3P:100-110 ---------
+ *  Every stride-th cell (S3P:1031: 4) of particle `particle`'s grid (global
+ * index; 0 on a PF_MAP_SHARED handle) whose value is above threshold (S3P:1033: 80), in index
+ * order, as the float32 triples the reference puts into sensor_msgs/PointCloud: (X*res, -Z*res,
+ * Y*res), the index split in the reference's double arithmetic. xyz_out: host float [capacity][3].
+ * *n_out = triples written (<= capacity); *total_out (may be NULL) = cells that qualified. */
+int pf_read_occupied(pf_handle* h, int32_t particle, int32_t threshold, int32_t stride, float* xyz_out,
+                     int64_t capacity, int64_t* n_out, int64_t* total_out);
+
 /* ---- multi-GPU: the exchange step inside the library ----------------------------
  * No counterpart in the reference (it is one process on one CPU thread, S3P:1107). One process per
  * GPU, one sharded handle per process. Rank 0 calls pf_comm_unique_id (128 bytes) and hands the id

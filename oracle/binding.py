@@ -199,3 +199,25 @@ class RingState:
         lib().pfo_ring_update.restype = C.c_int
         flags = lib().pfo_ring_update(C.byref(self.r), _p(grid), C.c_int64(len(cloud)), _p(cloud), _p(pos), _p(zyx))
         return flags, pos
+
+
+def depth_to_cloud(image_bytes, width=640, height=480, pool=4, focal=385.0 / 4.0):
+    if isinstance(image_bytes, (bytes, bytearray)):
+        image_bytes = np.frombuffer(image_bytes, np.uint8)
+    image_bytes = _c(image_bytes, np.uint8).reshape(-1)
+    assert len(image_bytes) == width * height * 2
+    out = np.empty(((width // pool) * (height // pool), 3), np.float64)
+    lib().pfo_depth_to_cloud.restype = C.c_int64
+    n = lib().pfo_depth_to_cloud(_p(image_bytes), width, height, pool, C.c_double(focal), _p(out))
+    return out[:n].copy()
+
+
+def read_occupied(grid, resolution=0.05, threshold=80, stride=4, cap=None):
+    grid = _c(grid, np.uint8)
+    gx, gy, gz = grid.shape
+    cap = cap if cap is not None else grid.size // stride + 1
+    out = np.empty((cap, 3), np.float32)
+    lib().pfo_read_occupied.restype = C.c_int64
+    n = lib().pfo_read_occupied(_p(grid), gx, gy, gz, C.c_double(resolution), threshold, stride, _p(out),
+                                C.c_int64(cap))
+    return out[:n].copy()

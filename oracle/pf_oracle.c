@@ -376,3 +376,58 @@ int pfo_ring_update(pfo_ring* r, uint8_t* grid, int64_t n, const double* cloud, 
     }
     return flags;
 }
+
+/* ---- depth front-end: S3P:562-612 -------------------------------------------------------- */
+int64_t pfo_depth_to_cloud(const uint8_t* image, int32_t width, int32_t height, int32_t pool,
+                           double focal, double* cloud_out) {
+    const int32_t res_h = width / pool, res_v = height / pool;         /* S3P:116-117 */
+    int64_t n = 0;
+    for (int32_t i = 0; i < res_v; i++) {
+        const double vertical = -1 * ((i + 1) - (res_v / 2)) / focal;  /* S3P:161 */
+        for (int32_t j = 0; j < res_h; j++) {
+            const double horizontal = ((j + 1) - (res_h / 2)) / focal; /* S3P:158 */
+            int int_sum = 0, devide_sum = 0;                           /* S3P:580-594 */
+            for (int32_t a = 0; a < pool; a++) {
+                int64_t k = ((int64_t)(i * pool + a) * width + (int64_t)j * pool) * 2;
+                for (int32_t b = 0; b < pool; b++) {
+                    const int v = (image[k + 1] << 8) | image[k];
+                    k += 2;
+                    int_sum += v;
+                    devide_sum += (v != 0) ? 1 : 0;
+                }
+            }
+            const int depth_y = devide_sum != 0 ? int_sum / devide_sum : 0;
+            const int depth_x = (int)(depth_y * horizontal);           /* S3P:567: double -> int */
+            const int depth_z = (int)(depth_y * vertical);             /* S3P:568 */
+            if (depth_y != 0) {                                        /* S3P:602-607 */
+                cloud_out[3 * n + 0] = depth_x / 1000.0;
+                cloud_out[3 * n + 1] = depth_y / 1000.0;
+                cloud_out[3 * n + 2] = depth_z / 1000.0;
+                n += 1;
+            }
+        }
+    }
+    return n;
+}
+
+/* ---- map read-out: S3P:1031-1051 --------------------------------------------------------- */
+int64_t pfo_read_occupied(const uint8_t* map, int32_t gx, int32_t gy, int32_t gz, double resolution,
+                          int32_t threshold, int32_t stride, float* xyz_out, int64_t cap) {
+    const int64_t elements = (int64_t)gx * gy * gz;
+    const double gyz = (double)gy * (double)gz, gzd = (double)gz;      /* S3P:104: (15/0.05)*(4/0.05) */
+    int64_t n = 0;
+    for (int64_t i = 0; i < elements; i += stride) {                   /* S3P:1031 */
+        if (map[i] > threshold) {                                      /* S3P:1033 */
+            const int x = (int)(i / gyz);                              /* S3P:104-106 */
+            const int y = (int)((i - x * gyz) / gzd);
+            const int z = (int)(i - x * gyz - y * gzd);
+            if (n < cap) {
+                xyz_out[3 * n + 0] = (float)(x * resolution);          /* S3P:1036-1038 */
+                xyz_out[3 * n + 1] = (float)(-z * resolution);
+                xyz_out[3 * n + 2] = (float)(y * resolution);
+            }
+            n += 1;
+        }
+    }
+    return n < cap ? n : cap;
+}

@@ -131,6 +131,24 @@ void pfo_ring_paint(const pfo_ring* r, uint8_t* grid);
 int pfo_ring_update(pfo_ring* r, uint8_t* grid, int64_t n, const double* cloud, double pos_scan[3],
                     const double zyx[3]);
 
+/* ---- depth front-end: S3P:116-124, 155-162, 562-612. PARITY UNPINNED (class
+ * members). image: height rows of width little-endian uint16 depths in millimetres (the bytes of
+ * sensor_msgs/Image, S3P:587); pooled pool x pool (S3P:580-594: integer mean that ignores zeros),
+ * pinhole tables from focal = the pooled focal length (S3P:124: 385/4), integer millimetre
+ * products truncated toward zero (S3P:567-568 assign a double to an int), then metres; pixels
+ * whose pooled depth is 0 are dropped, row-major order kept (S3P:598-611).
+ * cloud_out: [(width/pool)*(height/pool)][3]; returns the number of points. */
+int64_t pfo_depth_to_cloud(const uint8_t* image, int32_t width, int32_t height, int32_t pool,
+                           double focal, double* cloud_out);
+
+/* ---- map read-out for publishing: S3P:1031-1051 with reverse_index_conv_p S3P:100-110 (SURVEY
+ * 8f rank 4). Every stride-th cell above `threshold`, in index order, as the float32 triples the
+ * reference puts into sensor_msgs/PointCloud: (X*res, -Z*res, Y*res). The index is split with
+ * the reference's double arithmetic truncated to int. Returns the number of points written
+ * (at most cap). */
+int64_t pfo_read_occupied(const uint8_t* map, int32_t gx, int32_t gy, int32_t gz, double resolution,
+                          int32_t threshold, int32_t stride, float* xyz_out, int64_t cap);
+
 /* S3P:328-376: pose-lattice vote on a binary uint8 grid. Yaw hypothesis r is
  * zyx[0] + (yaw_k0 + yaw_kstep*r)*pi/180 (S3P:329: k0 = -6, kstep = 3, n_yaw = 5); translation
  * lattice n_t per axis over `length` (S3P:275, 279: 0.25, 5). sums[n_yaw*n_t^3] per hypothesis

@@ -26,7 +26,8 @@ SYMBOLS = (
     "pf_reset_local_map pf_stream pf_set_stream pf_synchronize pf_profile pf_kernel_time "
     "pfh_snapshot_beams pfh_predict pfh_draw_noise pfh_draw_uniform pfh_add_points_policy "
     "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init "
-    "pf_ring_default_params pf_ring_init pf_ring_paint pf_ring_update pf_ring_state").split()
+    "pf_ring_default_params pf_ring_init pf_ring_paint pf_ring_update pf_ring_state "
+    "pf_depth_to_cloud pf_read_occupied").split()
 
 
 class Config(C.Structure):
@@ -292,6 +293,28 @@ class Handle:
         idx = np.empty(n * cap, np.int32) if with_idx else None
         self._ck(lib().pf_ring_state(self._h, _p(counts), _p(lives), _p(pu), _p(eu), _p(idx)), "pf_ring_state")
         return counts, lives, pu, eu, (idx.reshape(n, cap) if with_idx else None)
+
+    def depth_to_cloud(self, image, width, height, pool=4, focal=385.0 / 4.0):
+        """image: the uint16 little-endian depth bytes (height*width*2). Returns float64 [n][3]."""
+        image = _c(np.frombuffer(image, np.uint8) if isinstance(image, (bytes, bytearray)) else image, np.uint8)
+        if image.size != width * height * 2:
+            raise PfError("image must hold width*height*2 bytes")
+        cap = (width // pool) * (height // pool) if pool > 0 else 0
+        out = np.empty((max(cap, 1), 3), np.float64)
+        n = C.c_int64(0)
+        self._ck(lib().pf_depth_to_cloud(self._h, _p(image), C.c_int32(width), C.c_int32(height), C.c_int32(pool),
+                                         C.c_double(focal), _p(out), C.c_int64(cap), C.byref(n)),
+                 "pf_depth_to_cloud")
+        return out[:n.value].copy()
+
+    def read_occupied(self, particle=0, threshold=80, stride=4, capacity=None):
+        """Returns (float32 [n][3], total qualifying cells)."""
+        cap = (self.elements + stride - 1) // stride if capacity is None and stride >= 1 else int(capacity or 0)
+        out = np.empty((max(cap, 1), 3), np.float32)
+        n = C.c_int64(0); total = C.c_int64(0)
+        self._ck(lib().pf_read_occupied(self._h, C.c_int32(particle), C.c_int32(threshold), C.c_int32(stride),
+                                        _p(out), C.c_int64(cap), C.byref(n), C.byref(total)), "pf_read_occupied")
+        return out[:n.value].copy(), total.value
 
     def write_local_map(self, src):
         src = _c(src, np.int8).reshape(-1)

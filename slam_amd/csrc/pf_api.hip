@@ -920,6 +920,7 @@ int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const dou
     return PF_OK;
 }
 
+static int grow_scratch(pf_handle* h, size_t need);
 int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const double pos[3],
                  const double zyx[3], int32_t n_yaw, int32_t yaw_k0, int32_t yaw_kstep,
                  int32_t n_t, double length, int32_t* sums_out, int64_t* best_out) {
@@ -961,14 +962,7 @@ int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const dou
     const size_t nb_m = sizeof(double) * mats.size(), nb_t = sizeof(double) * trans.size();
     const size_t nb_r = sizeof(double) * 3 * (size_t)n_yaw * (size_t)(n_points ? n_points : 1);
     const size_t nb_s = sizeof(int32_t) * (size_t)nh;
-    const size_t need = nb_m + nb_t + nb_r + nb_s + 64;
-    if (need > h->vote_cap) {
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (h->vote_scratch) (void)hipFree(h->vote_scratch);
-        h->vote_scratch = nullptr; h->vote_cap = 0;
-        HIP_TRY(h, hipMalloc((void**)&h->vote_scratch, need));
-        h->vote_cap = need;
-    }
+    if (int rc = grow_scratch(h, nb_m + nb_t + nb_r + nb_s + 64)) return rc;
     char* dev = h->vote_scratch;
     double* d_m = (double*)dev; double* d_t = (double*)(dev + nb_m);
     double* d_r = (double*)(dev + nb_m + nb_t); int32_t* d_s = (int32_t*)(dev + nb_m + nb_t + nb_r);
@@ -990,6 +984,83 @@ int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const dou
         if (sums[(size_t)k] > best_sum) { best_sum = sums[(size_t)k]; best = k; }
     *best_out = best;
     if (sums_out) memcpy(sums_out, sums.data(), nb_s);
+    return PF_OK;
+}
+
+// Device scratch shared by the calls that are not part of the per-step loop (pf_scan_vote,
+// pf_depth_to_cloud, pf_read_occupied): one allocation, grown on demand, kept by the handle.
+static int grow_scratch(pf_handle* h, size_t need) {
+    if (need <= h->vote_cap) return PF_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->vote_scratch) (void)hipFree(h->vote_scratch);
+    h->vote_scratch = nullptr; h->vote_cap = 0;
+    HIP_TRY(h, hipMalloc((void**)&h->vote_scratch, need));
+    h->vote_cap = need;
+    return PF_OK;
+}
+static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+int pf_depth_to_cloud(pf_handle* h, const uint8_t* image, int32_t width, int32_t height, int32_t pool,
+                      double focal, double* cloud_out, int64_t capacity, int64_t* n_out) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, image && cloud_out && n_out, "null argument");
+    NEED(h, pool >= 1 && pool <= 16 && width >= pool && height >= pool && width <= 16384 && height <= 16384,
+         "image size / pool factor");
+    NEED(h, focal > 0 && focal < 1.0e9, "focal length");
+    const int64_t npix = (int64_t)(width / pool) * (height / pool);
+    NEED(h, capacity >= npix, "cloud_out holds fewer than (width/pool)*(height/pool) points");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t nb_i = up256((size_t)width * height * 2), nb_d = up256(sizeof(int4) * (size_t)npix);
+    const size_t nb_c = up256(sizeof(double) * 3 * (size_t)npix);
+    if (int rc = grow_scratch(h, nb_i + nb_d + nb_c + 256)) return rc;
+    char* dev = h->vote_scratch;
+    uint8_t* d_img = (uint8_t*)dev; int4* d_pix = (int4*)(dev + nb_i);
+    double* d_cloud = (double*)(dev + nb_i + nb_d); int32_t* d_n = (int32_t*)(dev + nb_i + nb_d + nb_c);
+    int32_t n = 0;
+    HIP_TRY(h, hipMemcpyAsync(d_img, image, (size_t)width * height * 2, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, pfk_depth_to_cloud(h->stream, d_img, width, height, pool, focal, d_pix, d_cloud, d_n));
+    HIP_TRY(h, hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (n > 0) {
+        HIP_TRY(h, hipMemcpyAsync(cloud_out, d_cloud, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    *n_out = n;
+    return PF_OK;
+}
+
+int pf_read_occupied(pf_handle* h, int32_t particle, int32_t threshold, int32_t stride, float* xyz_out,
+                     int64_t capacity, int64_t* n_out, int64_t* total_out) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, n_out && capacity >= 0 && (capacity == 0 || xyz_out), "null argument");
+    NEED(h, stride >= 1, "stride");
+    NEED(h, capacity <= (int64_t)1 << 28, "capacity beyond 2^28 points");
+    const uint8_t* grid = h->maps;
+    if (h->cfg.map_mode == PF_MAP_SHARED) NEED(h, particle == 0, "a PF_MAP_SHARED handle has one grid: particle must be 0");
+    else {
+        NEED(h, particle >= h->offset && particle < h->offset + h->P, "particle is not on this handle");
+        grid += h->slab * (unsigned long long)(particle - h->offset);
+    }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, wait_map_writes(h));
+    const long long cand = (h->elements + stride - 1) / stride;
+    const int nb = (int)((cand + 1023) / 1024);
+    const size_t nb_b = up256(sizeof(int32_t) * (size_t)nb), nb_x = up256(sizeof(float) * 3 * (size_t)capacity);
+    if (int rc = grow_scratch(h, nb_b + nb_x + 256)) return rc;
+    char* dev = h->vote_scratch;
+    int32_t* d_b = (int32_t*)dev; float* d_x = (float*)(dev + nb_b); int32_t* d_n = (int32_t*)(dev + nb_b + nb_x);
+    int32_t total = 0;
+    HIP_TRY(h, pfk_read_occupied(h->stream, grid, h->elements, stride, threshold, h->cfg.grid_y, h->cfg.grid_z,
+                                 h->cfg.resolution, d_b, nb, d_n, d_x, capacity));
+    HIP_TRY(h, hipMemcpyAsync(&total, d_n, sizeof total, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int64_t n = total < capacity ? total : capacity;
+    if (n > 0) {
+        HIP_TRY(h, hipMemcpyAsync(xyz_out, d_x, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    *n_out = n;
+    if (total_out) *total_out = total;
     return PF_OK;
 }
 

@@ -165,3 +165,13 @@ hipError_t pfk_ring_fill(hipStream_t st, const double* points, int n, PfUpdatePa
                          int32_t* count_out);
 hipError_t pfk_ring_shift(hipStream_t st, int32_t* slot, int count, long long corr, long long elements,
                           int32_t* count_out);
+
+// Depth front-end (S3P:562-612). image: device copy of the uint16 little-endian depth bytes;
+// dpix: int4 [npix] scratch; cloud: double [npix][3]; *count_out = points written.
+hipError_t pfk_depth_to_cloud(hipStream_t st, const uint8_t* image, int width, int height, int pool,
+                              double focal, int4* dpix, double* cloud, int32_t* count_out);
+// Map read-out (S3P:1031-1051). bcnt: int32 [nb], nb = ceil(ceil(elements/stride)/1024);
+// *total_out = qualifying cells (may exceed cap; only the first cap are written).
+hipError_t pfk_read_occupied(hipStream_t st, const uint8_t* map, long long elements, int stride,
+                             int threshold, int gy, int gz, double res, int32_t* bcnt, int nb,
+                             int32_t* total_out, float* xyz, long long cap);

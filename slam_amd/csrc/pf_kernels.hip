@@ -970,3 +970,146 @@ hipError_t pfk_ring_shift(hipStream_t st, int32_t* slot, int count, long long co
     hipLaunchKernelGGL(k_ring_shift, dim3(1), dim3(1024), 0, st, slot, count, corr, elements, count_out);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------
+// Depth front-end: S3P:562-612. One thread per pooled pixel: integer mean of
+// the pool x pool little-endian uint16 depths that are not 0 (S3P:580-594), millimetre products
+// with the pinhole tables truncated toward zero (S3P:567-568); then an order-preserving
+// compaction of the pixels with a depth (S3P:598-611) in one workgroup.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_depth_pool(const uint8_t* __restrict__ image, int width,
+                                                    int res_h, int res_v, int pool, double focal,
+                                                    int4* __restrict__ dpix) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= res_h * res_v) return;
+    const int i = p / res_h, j = p - i * res_h;
+    int int_sum = 0, devide_sum = 0;
+    for (int a = 0; a < pool; ++a) {
+        const uint8_t* row = image + ((size_t)(i * pool + a) * width + (size_t)j * pool) * 2;
+        for (int b = 0; b < pool; ++b) {
+            const int v = ((int)row[2 * b + 1] << 8) | (int)row[2 * b];      // S3P:587
+            int_sum += v;
+            devide_sum += v != 0 ? 1 : 0;
+        }
+    }
+    const int depth_y = devide_sum != 0 ? int_sum / devide_sum : 0;         // S3P:593
+    const double horizontal = ((j + 1) - (res_h / 2)) / focal;             // S3P:158
+    const double vertical = -1 * ((i + 1) - (res_v / 2)) / focal;          // S3P:161
+    dpix[p] = make_int4((int)(depth_y * horizontal), depth_y, (int)(depth_y * vertical), 0);
+}
+__global__ __launch_bounds__(1024) void k_depth_compact(const int4* __restrict__ dpix, int npix,
+                                                        double* __restrict__ cloud, int32_t* count_out) {
+    __shared__ int wtot[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < npix; t0 += 1024) {
+        const int p = t0 + tid;
+        int4 d = make_int4(0, 0, 0, 0);
+        if (p < npix) d = dpix[p];
+        const bool keep = d.y != 0;                                         // S3P:602
+        const unsigned long long m = __ballot(keep);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wtot[wv] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int k = 0; k < wv; ++k) off += wtot[k];
+        if (keep) {
+            double* o = cloud + 3 * (size_t)(off + rank);
+            o[0] = d.x / 1000.0; o[1] = d.y / 1000.0; o[2] = d.z / 1000.0;   // S3P:603-605
+        }
+        __syncthreads();
+        if (tid == 0) { int sum = 0; for (int k = 0; k < 16; ++k) sum += wtot[k]; base_s += sum; }
+        __syncthreads();
+    }
+    if (tid == 0) *count_out = base_s;
+}
+hipError_t pfk_depth_to_cloud(hipStream_t st, const uint8_t* image, int width, int height, int pool,
+                              double focal, int4* dpix, double* cloud, int32_t* count_out) {
+    const int res_h = width / pool, res_v = height / pool, npix = res_h * res_v;
+    if (npix <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_depth_pool, dim3((npix + 255) / 256), dim3(256), 0, st, image, width, res_h, res_v,
+                       pool, focal, dpix);
+    hipLaunchKernelGGL(k_depth_compact, dim3(1), dim3(1024), 0, st, dpix, npix, cloud, count_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Map read-out for publishing: S3P:1031-1051. Every stride-th cell above the
+// threshold, in index order, as the float triples of the reference's point cloud message
+// (X*res, -Z*res, Y*res; the index split of reverse_index_conv_p, S3P:100-110, in its double
+// arithmetic). Per-workgroup counts, one scanning workgroup, ranked scatter.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_occ_count(const uint8_t* __restrict__ map, long long elements,
+                                                    int stride, int threshold, int32_t* __restrict__ bcnt) {
+    __shared__ int wtot[16];
+    const long long c = (long long)blockIdx.x * 1024 + threadIdx.x;       // candidate number
+    const long long i = c * stride;
+    const bool keep = i < elements && (int)map[i] > threshold;
+    const int n = __popcll(__ballot(keep));
+    if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) { int sum = 0; for (int k = 0; k < 16; ++k) sum += wtot[k]; bcnt[blockIdx.x] = sum; }
+}
+__global__ __launch_bounds__(1024) void k_occ_scan(int32_t* bcnt, int nb, int32_t* total_out) {
+    __shared__ int wtot[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < nb; t0 += 1024) {
+        const int k = t0 + tid;
+        const int v = k < nb ? bcnt[k] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wtot[wv] = inc;
+        __syncthreads();
+        int off = carry_s;
+        for (int q = 0; q < wv; ++q) off += wtot[q];
+        if (k < nb) bcnt[k] = off + inc - v;                               // exclusive
+        __syncthreads();
+        if (tid == 0) { int sum = 0; for (int q = 0; q < 16; ++q) sum += wtot[q]; carry_s += sum; }
+        __syncthreads();
+    }
+    if (tid == 0) *total_out = carry_s;
+}
+__global__ __launch_bounds__(1024) void k_occ_scatter(const uint8_t* __restrict__ map, long long elements,
+                                                      int stride, int threshold,
+                                                      const int32_t* __restrict__ boff, double gyz,
+                                                      double gzd, double res, long long cap,
+                                                      float* __restrict__ xyz) {
+    __shared__ int wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long c = (long long)blockIdx.x * 1024 + tid;
+    const long long i = c * stride;
+    const bool keep = i < elements && (int)map[i] > threshold;
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wtot[wv] = __popcll(m);
+    __syncthreads();
+    if (!keep) return;
+    long long dst = boff[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+    for (int k = 0; k < wv; ++k) dst += wtot[k];
+    if (dst >= cap) return;
+    const double id = (double)i;
+    const int x = (int)(id / gyz);                                         // S3P:104-106
+    const int y = (int)((id - x * gyz) / gzd);
+    const int z = (int)(id - x * gyz - y * gzd);
+    xyz[3 * dst + 0] = (float)(x * res);                                   // S3P:1036-1038
+    xyz[3 * dst + 1] = (float)(-z * res);
+    xyz[3 * dst + 2] = (float)(y * res);
+}
+hipError_t pfk_read_occupied(hipStream_t st, const uint8_t* map, long long elements, int stride,
+                             int threshold, int gy, int gz, double res, int32_t* bcnt, int nb,
+                             int32_t* total_out, float* xyz, long long cap) {
+    if (nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_occ_count, dim3(nb), dim3(1024), 0, st, map, elements, stride, threshold, bcnt);
+    hipLaunchKernelGGL(k_occ_scan, dim3(1), dim3(1024), 0, st, bcnt, nb, total_out);
+    hipLaunchKernelGGL(k_occ_scatter, dim3(nb), dim3(1024), 0, st, map, elements, stride, threshold, bcnt,
+                       (double)gy * (double)gz, (double)gz, res, cap, xyz);
+    return hipGetLastError();
+}

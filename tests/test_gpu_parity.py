@@ -727,3 +727,72 @@ def test_keyframe_ring_matches_oracle():
         assert np.array_equal(got, want) and gbest == wbest and want.max() > 0
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("shape", [(640, 480, 4), (50, 31, 3), (64, 48, 1), (16, 16, 16)])
+def test_depth_front_end_matches_oracle(shape):
+    """S3P:562-612: pooled depth image -> sensor-frame cloud, bit-exact against
+    the restatement (parity unpinned by the reference: a ROS callback). Images with holes (zero
+    depth), saturated pixels and fully empty pooled blocks; ragged sizes drop the remainder
+    columns/rows like the reference's res_h = width/pool."""
+    width, height, pool = shape
+    rng = np.random.default_rng(width * 7 + pool)
+    img = rng.integers(300, 9000, (height, width)).astype(np.uint16)
+    img[rng.random((height, width)) < 0.35] = 0
+    img[rng.random((height, width)) < 0.01] = 65535
+    img[: height // 3, : width // 4] = 0                      # empty pooled blocks
+    raw = np.frombuffer(img.astype("<u2").tobytes(), np.uint8)
+    focal = 385.0 / pool
+    want = O.depth_to_cloud(raw, width, height, pool, focal)
+    h = capi.Handle(_shared_cfg(1, (16, 16, 16)))
+    try:
+        got = h.depth_to_cloud(raw, width, height, pool, focal)
+        assert got.shape == want.shape and len(want) > 0
+        assert np.array_equal(got, want)
+        empty = h.depth_to_cloud(np.zeros(width * height * 2, np.uint8), width, height, pool, focal)
+        assert empty.shape == (0, 3)
+        with pytest.raises(capi.PfError):
+            h.depth_to_cloud(raw, width, height, 0, focal)
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("dims,stride", [((200, 200, 80), 4), ((31, 23, 19), 4), ((64, 48, 40), 1),
+                                         ((33, 17, 9), 7)])
+def test_map_read_out_matches_oracle(dims, stride):
+    """S3P:1031-1051: the published point cloud of the best particle's grid,
+    bit-exact float32 triples in index order; truncation at the caller's capacity; per-particle
+    slabs picked by global particle index."""
+    rng = np.random.default_rng(dims[0] + stride)
+    grid = rng.integers(0, 256, dims).astype(np.uint8)
+    grid[rng.random(dims) < 0.7] = 50
+    want = O.read_occupied(grid, 0.05, 80, stride)
+    h = capi.Handle(_shared_cfg(1, dims))
+    try:
+        h.broadcast_map(grid)
+        got, total = h.read_occupied(0, 80, stride)
+        assert total == len(want) and got.shape == want.shape
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        few, total2 = h.read_occupied(0, 80, stride, capacity=5)
+        assert total2 == total and np.array_equal(few, want[:5])
+        none, _ = h.read_occupied(0, 255, stride)
+        assert none.shape == (0, 3)
+        with pytest.raises(capi.PfError):
+            h.read_occupied(1, 80, stride)
+    finally:
+        h.close()
+    if dims[0] > 40:
+        return
+    P = 3
+    cfg = capi.default_config(n_particles=P, map_mode=capi.PF_MAP_PER_PARTICLE, grid_x=dims[0], grid_y=dims[1],
+                              grid_z=dims[2], max_beams=64, max_points=64)
+    h = capi.Handle(cfg)
+    try:
+        grids = [np.roll(grid, 3 * i, axis=0) for i in range(P)]
+        for i in range(P):
+            h.write_map(i, grids[i])
+        for i in range(P):
+            got, _ = h.read_occupied(i, 80, stride)
+            assert np.array_equal(got, O.read_occupied(grids[i], 0.05, 80, stride))
+    finally:
+        h.close()

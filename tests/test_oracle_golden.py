@@ -193,3 +193,44 @@ def test_ring_restatement_invariants():
     assert flags == 3 and np.array_equal(pos, centre)
     assert not grid.any()                                   # S3P:498-500 erased what was painted
     assert ring.life.tolist() == [4, 5, -2]                 # a second slot was taken (6), then all aged
+
+
+def test_read_out_restatement_against_reference_index_split(golden_dir):
+    """pfo_read_occupied (S3P:1031-1051): its index split is the reference's reverse_index_conv_p
+    (S3P:100-110), whose outputs for 200 indices of the reference's 200 x 200 x 80 grid are in
+    helpers.npz (`rev`, produced by the reference's own function); the coordinate swap and signs
+    are S3P:1036-1038. Threshold and stride behaviour on the same grid."""
+    g = load(golden_dir, "helpers.npz")
+    js, rev = g["js"].astype(np.int64), g["rev"].astype(np.int64)
+    gx = int(js.max() // 16000 + 1)
+    grid = np.zeros((gx, 200, 80), np.uint8)
+    grid.reshape(-1)[js] = 81
+    got = O.read_occupied(grid, 0.05, 80, 1)
+    o = np.argsort(js)
+    u = np.concatenate([[True], np.diff(js[o]) != 0])
+    r = rev[o][u]
+    want = np.stack([(r[:, 0] * 0.05), (-r[:, 2] * 0.05), (r[:, 1] * 0.05)], 1).astype(np.float32)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    grid.reshape(-1)[js] = 80                                   # not above the threshold
+    assert len(O.read_occupied(grid, 0.05, 80, 1)) == 0
+    grid.reshape(-1)[js] = 255
+    sel = np.unique(js[js % 4 == 0])
+    assert len(O.read_occupied(grid, 0.05, 80, 4)) == len(sel)
+    assert len(O.read_occupied(grid, 0.05, 80, 4, cap=3)) == min(3, len(sel))
+
+
+def test_depth_front_end_restatement_by_hand():
+    """pfo_depth_to_cloud (S3P:562-612; parity unpinned, a ROS callback of class Slam): an 8 x 8
+    image pooled 4 x 4 worked by hand. Block (0,0): 3 non-zero depths 1000, 2000, 2001 -> integer
+    mean 1667; block (0,1): all zero -> dropped; block (1,0): one depth 65535; block (1,1): 16 x
+    1500. Tables: horizontal[j] = ((j+1) - 1)/focal, vertical[i] = -((i+1) - 1)/focal."""
+    img = np.zeros((8, 8), np.uint16)
+    img[0, 0], img[1, 2], img[3, 3] = 1000, 2000, 2001
+    img[5, 1] = 65535
+    img[4:, 4:] = 1500
+    focal = 2.0
+    cloud = O.depth_to_cloud(img.astype("<u2").tobytes(), 8, 8, 4, focal)
+    want = np.array([[int(1667 * 0.0), 1667, int(1667 * -0.0)],
+                     [int(65535 * 0.0), 65535, int(65535 * -0.5)],
+                     [int(1500 * 0.5), 1500, int(1500 * -0.5)]]) / 1000.0
+    assert np.array_equal(cloud, want)

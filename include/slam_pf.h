@@ -272,11 +272,28 @@ void pfh_draw_uniform(uint32_t seed, int64_t n, double* u);
 int pfh_add_points_policy(const double pose[4], double last[4], double threshold);
 /* The pose hypothesis behind an index pf_scan_vote returns (loop order r, x, y, z of S3P:328-348):
  * out = {Tx_loc, Ty_loc, Tz_loc, rot_z_loc} as S3P:366-371 would have stored them. Returns 0, or -1
- * when `index` is outside the lattice (pf_scan_vote's "no vote" -1 included: out = the input pose,
- * which is what S3P:326-327 initialises the result to). */
+ * when `index` is outside the lattice (pf_scan_vote's "no vote" -1 included): out = the input pose
+ * then. The reference leaves Tx_loc ... rot_z_loc at the previous frame's values in that case
+ * (members, S3P:365-372 not entered), which equal the input pose unless the ring recentred in
+ * between (S3P:520-524); a caller that wants exactly that keeps its previous `out` on -1. */
 int pfh_vote_hypothesis(int64_t index, const double pos[3], const double zyx[3], double resolution,
                         int32_t n_yaw, int32_t yaw_k0, int32_t yaw_kstep, int32_t n_t, double length,
                         double out[4]);
+/* S3P:315-319 and S3P:666-669: n draws of uniform_int_distribution<>(0, hi), hi INCLUSIVE as the
+ * reference writes it (index hi of the cloud is one past the last point: the caller decides what
+ * lives there), from one mt19937(seed). libstdc++'s algorithm, like the other pfh_draw_*. */
+void pfh_draw_indices(uint32_t seed, int64_t n, int32_t hi, int32_t* idx);
+/* S3P:379-404, the epilogue of scan_localization(): loc = {Tx_loc, Ty_loc, Tz_loc, rot_z_loc}
+ * (pfh_vote_hypothesis). pos_scan[3] and *yaw_scan (euler_zyx_scan[0]) are in/out; gyr_yaw =
+ * gyr_acc_filter_zyx[0], *gyr_yaw_old = euler_zyx_diff_gyr_old (in/out). Outputs:
+ * pos_xyz_diff_scan[3], euler_zyx_diff_scan[0], euler_zyx_diff. */
+void pfh_vote_epilogue(double pos_scan[3], double* yaw_scan, const double loc[4], double gyr_yaw,
+                       double* gyr_yaw_old, double pos_diff_out[3], double* yaw_diff_scan_out,
+                       double* yaw_diff_out);
+/* S3P:207-222, the pose message convention: position (x, -z, y), orientation (w, x, y, z) =
+ * (cos(a), 0, sin(a), 0) with a = (-yaw - pi/2)/2. */
+void pfh_pose_message(const double pos[3], double yaw, double position_out[3],
+                      double orientation_wxyz_out[4]);
 /* S3P:805-812 on the caller's own per-particle records. */
 void pfh_permute(int64_t n, const int32_t* slot_anc, void* records, size_t width);
 

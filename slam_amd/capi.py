@@ -27,7 +27,7 @@ SYMBOLS = (
     "pfh_snapshot_beams pfh_predict pfh_draw_noise pfh_draw_uniform pfh_add_points_policy "
     "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init "
     "pf_ring_default_params pf_ring_init pf_ring_paint pf_ring_update pf_ring_state "
-    "pf_depth_to_cloud pf_read_occupied").split()
+    "pf_depth_to_cloud pf_read_occupied pfh_draw_indices pfh_vote_epilogue pfh_pose_message").split()
 
 
 class Config(C.Structure):
@@ -403,6 +403,31 @@ def vote_hypothesis(index, pos, zyx, resolution=0.05, n_yaw=5, yaw_k0=-6, yaw_ks
     rc = lib().pfh_vote_hypothesis(C.c_int64(int(index)), _p(pos), _p(zyx), C.c_double(resolution),
                                    n_yaw, yaw_k0, yaw_kstep, n_t, C.c_double(length), _p(out))
     return out if rc == 0 else None
+
+
+def draw_indices(seed, n, hi):
+    """n draws of uniform_int_distribution<>(0, hi) (inclusive) from mt19937(seed): S3P:315-319, 666-669."""
+    idx = np.empty(n, np.int32)
+    lib().pfh_draw_indices(C.c_uint32(seed), C.c_int64(n), C.c_int32(hi), _p(idx))
+    return idx
+
+
+def vote_epilogue(pos_scan, yaw_scan, loc, gyr_yaw, gyr_yaw_old):
+    """S3P:379-404. Returns (pos_scan, yaw_scan, gyr_yaw_old, pos_diff[3], yaw_diff_scan, yaw_diff)."""
+    pos = np.array(pos_scan, np.float64); loc = _c(loc, np.float64)
+    yaw = C.c_double(yaw_scan); old = C.c_double(gyr_yaw_old)
+    pd = np.empty(3, np.float64); ds = C.c_double(0); d = C.c_double(0)
+    lib().pfh_vote_epilogue(_p(pos), C.byref(yaw), _p(loc), C.c_double(gyr_yaw), C.byref(old), _p(pd),
+                            C.byref(ds), C.byref(d))
+    return pos, yaw.value, old.value, pd, ds.value, d.value
+
+
+def pose_message(pos, yaw):
+    """S3P:207-222: (position[3], orientation wxyz[4]) of the published PoseStamped."""
+    pos = _c(pos, np.float64)
+    p = np.empty(3, np.float64); q = np.empty(4, np.float64)
+    lib().pfh_pose_message(_p(pos), C.c_double(yaw), _p(p), _p(q))
+    return p, q
 
 
 def comm_unique_id():

@@ -121,6 +121,13 @@ struct pf_handle {
     ncclComm_t comm = nullptr;
     int comm_world = 1;
     int2* scores_all = nullptr;        // [Pg]
+    // The pose blocks pf_resample needs are final once the caller has predicted, which the
+    // reference does before the weights (S3P:911-914 precede S3P:920): pf_weights then issues both
+    // all-gathers as one RCCL group (one launch, one latency) and pf_resample finds the blocks
+    // there. A predict between the two calls clears the flag and pf_resample gathers itself.
+    // SLAM_PF_TWO_GATHERS=1: always one collective per call, as before.
+    bool poses_gathered = false;
+    bool group_gathers = true;
     double* poses_all = nullptr;       // [world][9][P]
     // profiling
     bool profile = false;
@@ -211,6 +218,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -229,6 +238,8 @@ Rccl& rccl() {
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
     return r;
 }
@@ -426,6 +437,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->beams_occ_g, (size_t)c.max_beams / PF_BEAM_GROUP + 1));
     if (const char* e = getenv("SLAM_PF_GRAPH")) h->use_graphs = atoi(e) != 0;
     if (const char* e = getenv("SLAM_PF_SIDE")) h->use_side = atoi(e) != 0;
+    if (const char* e = getenv("SLAM_PF_TWO_GATHERS")) h->group_gathers = atoi(e) == 0;
     if (const char* e = getenv("SLAM_PF_CHUNKS")) h->tune_chunks = atoi(e);
     if (const char* e = getenv("SLAM_PF_EXACT_MEASURE")) h->force_exact_measure = atoi(e);
     CREATE_TRY(dalloc(&h->partial, (size_t)h->max_chunks * P));
@@ -500,6 +512,7 @@ int pf_predict(pf_handle* h, const double* x, const double* y, const double* z, 
                               hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, drop_counted_keys(h));
     h->order_dirty = true;
+    h->poses_gathered = false;
     return PF_OK;
 }
 
@@ -511,6 +524,7 @@ int pf_predict_device(pf_handle* h, const void* pose_block_dev) {
                               hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, drop_counted_keys(h));
     h->order_dirty = true;
+    h->poses_gathered = false;
     return PF_OK;
 }
 
@@ -768,9 +782,16 @@ int pf_weights(pf_handle* h, const void* scores_global_dev) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const int2* sc = scores_global_dev ? (const int2*)scores_global_dev : h->scores;
     if (!scores_global_dev && h->comm) {              // C1: 8 B per particle, rank order
-        const ncclResult_t r = rccl().AllGather(h->scores, h->scores_all, 2 * (size_t)h->P, ncclInt32,
-                                                h->comm, h->stream);
+        const bool both = h->group_gathers && rccl().GroupStart && rccl().GroupEnd;
+        ncclResult_t r = both ? rccl().GroupStart() : ncclSuccess;
+        if (r == ncclSuccess)
+            r = rccl().AllGather(h->scores, h->scores_all, 2 * (size_t)h->P, ncclInt32, h->comm, h->stream);
+        if (r == ncclSuccess && both)                 // C2 rides along: 72 B per particle
+            r = rccl().AllGather(h->pose, h->poses_all, PF_POSE_ROWS * (size_t)h->P, ncclFloat64, h->comm,
+                                 h->stream);
+        if (both) { const ncclResult_t e = rccl().GroupEnd(); if (r == ncclSuccess) r = e; }
         if (r != ncclSuccess) return fail(h, PF_ERR_HIP, "pf_weights: ncclAllGather: %s", rccl().GetErrorString(r));
+        h->poses_gathered = both;
         sc = h->scores_all;
     }
     {
@@ -793,11 +814,14 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
         return fail(h, PF_ERR_ARG, "pf_resample: sharded handle needs the gathered pose blocks (or pf_comm_init)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (!poses_global_dev && h->comm) {               // C2: the 72-B pose blocks, rank order
-        const ncclResult_t r = rccl().AllGather(h->pose, h->poses_all, PF_POSE_ROWS * (size_t)h->P,
-                                                ncclFloat64, h->comm, h->stream);
-        if (r != ncclSuccess) return fail(h, PF_ERR_HIP, "pf_resample: ncclAllGather: %s", rccl().GetErrorString(r));
+        if (!h->poses_gathered) {                     // (else pf_weights' group already brought them)
+            const ncclResult_t r = rccl().AllGather(h->pose, h->poses_all, PF_POSE_ROWS * (size_t)h->P,
+                                                    ncclFloat64, h->comm, h->stream);
+            if (r != ncclSuccess) return fail(h, PF_ERR_HIP, "pf_resample: ncclAllGather: %s", rccl().GetErrorString(r));
+        }
         poses_global_dev = h->poses_all;
     }
+    h->poses_gathered = false;
     if (u) {
         HIP_TRY(h, hipMemcpyAsync(h->u, u, sizeof(double) * (size_t)h->Pg, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));

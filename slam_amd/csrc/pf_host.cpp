@@ -87,6 +87,45 @@ int pfh_vote_hypothesis(int64_t index, const double pos[3], const double zyx[3],
     return 0;
 }
 
+void pfh_draw_indices(uint32_t seed, int64_t n, int32_t hi, int32_t* idx) {
+    // S3P:315-319 (the 500 scan points of the vote) and S3P:666-669 (the 2400 ray targets): one
+    // mt19937, uniform_int_distribution<>(0, hi) with hi INCLUSIVE as the reference writes it.
+    std::mt19937 gen(seed);
+    std::uniform_int_distribution<> distr(0, hi);
+    for (int64_t i = 0; i < n; ++i) idx[i] = distr(gen);
+}
+
+void pfh_vote_epilogue(double pos_scan[3], double* yaw_scan, const double loc[4], double gyr_yaw,
+                       double* gyr_yaw_old, double pos_diff_out[3], double* yaw_diff_scan_out,
+                       double* yaw_diff_out) {
+    const double pi = 2 * acos(0.0);                                          // S3P:24
+    const double e0 = *yaw_scan;
+    pos_diff_out[0] = cos(-e0) * (loc[0] - pos_scan[0]) - sin(-e0) * (loc[1] - pos_scan[1]);   // S3P:379
+    pos_diff_out[1] = sin(-e0) * (loc[0] - pos_scan[0]) + cos(-e0) * (loc[1] - pos_scan[1]);   // S3P:380
+    pos_diff_out[2] = loc[2] - pos_scan[2];                                   // S3P:381
+    const double diff_scan = loc[3] - e0;                                     // S3P:382
+    *yaw_scan = loc[3];                                                       // S3P:383-386
+    pos_scan[0] = loc[0]; pos_scan[1] = loc[1]; pos_scan[2] = loc[2];
+    double diff_gyr;
+    if (fabs(*gyr_yaw_old - gyr_yaw) < pi) diff_gyr = gyr_yaw - *gyr_yaw_old;                  // S3P:393-402
+    else if (gyr_yaw < 0) diff_gyr = 2 * pi + gyr_yaw - *gyr_yaw_old;
+    else diff_gyr = -2 * pi + gyr_yaw - *gyr_yaw_old;
+    *gyr_yaw_old = gyr_yaw;                                                   // S3P:403
+    *yaw_diff_scan_out = diff_scan;
+    *yaw_diff_out = (diff_gyr + diff_scan) / 2;                               // S3P:404
+}
+
+void pfh_pose_message(const double pos[3], double yaw, double position_out[3], double orientation_wxyz_out[4]) {
+    const double pi = 2 * acos(0.0);
+    orientation_wxyz_out[0] = cos((-yaw - pi / 2) / 2);                       // S3P:212-215
+    orientation_wxyz_out[1] = 0;
+    orientation_wxyz_out[2] = sin((-yaw - pi / 2) / 2);
+    orientation_wxyz_out[3] = 0;
+    position_out[0] = pos[0];                                                 // S3P:216-218
+    position_out[1] = -pos[2];
+    position_out[2] = pos[1];
+}
+
 void pfh_permute(int64_t n, const int32_t* slot_anc, void* records, size_t width) {
     char* r = (char*)records;                              // S3P:805-812
     for (int64_t i = 0; i < n; ++i)

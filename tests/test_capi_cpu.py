@@ -136,3 +136,59 @@ def test_resample_oracle_properties():
     w = np.array([0.25, 0.25, 0.25, 0.25])
     d, sa, best, nohit = O.resample(w.copy(), np.array([0.0, 0.25, 0.5, 1.0]), 2)
     assert nohit == 4 and np.array_equal(d, np.arange(4)) and np.array_equal(sa, np.arange(4))
+
+
+def _mt19937_raw(seed, n):
+    bg = np.random.MT19937()
+    bg._legacy_seeding(seed)                      # init_genrand(seed), what std::mt19937(seed) does
+    return bg.random_raw(n).astype(np.uint64)
+
+
+def test_draw_indices_is_libstdcxx_uniform_int():
+    """pfh_draw_indices (S3P:315-319, 666-669): libstdc++ 11's uniform_int_distribution over a
+    32-bit engine (bits/uniform_int_dist.h: Lemire's multiply-shift with rejection of the short
+    low words), restated here on numpy's raw mt19937 stream; hi is inclusive."""
+    assert int(_mt19937_raw(5489, 1)[0]) == 3499211612          # the standard's known first output
+    for seed, hi, n in ((7, 19199, 2400), (11, 499, 500), (3, 0, 5), (5, 2, 4000)):
+        raw = _mt19937_raw(seed, 2 * n + 64)
+        rng_ = hi + 1
+        want, k = [], 0
+        while len(want) < n:
+            prod = int(raw[k]) * rng_; k += 1
+            low = prod & 0xFFFFFFFF
+            if low < rng_:
+                thr = ((1 << 32) - rng_) % rng_
+                while low < thr:
+                    prod = int(raw[k]) * rng_; k += 1
+                    low = prod & 0xFFFFFFFF
+            want.append(prod >> 32)
+        got = capi.draw_indices(seed, n, hi)
+        assert np.array_equal(got, np.array(want, np.int32))
+        assert got.min() >= 0 and got.max() <= hi
+    assert capi.draw_indices(5, 4000, 2).max() == 2             # inclusive
+
+
+def test_vote_epilogue_and_pose_message_follow_the_reference_formulas():
+    """pfh_vote_epilogue (S3P:379-404) and pfh_pose_message (S3P:207-222) against the formulas
+    written out with numpy, all three branches of the gyro unwrap."""
+    pi = 2 * np.arccos(0.0)
+    for gyr, old in ((0.3, 0.1), (-3.0, 3.0), (3.0, -3.0)):
+        pos0 = np.array([4.0, 5.0, 1.5]); e0 = 0.7
+        loc = np.array([4.1, 4.95, 1.55, 0.7 + 3 * pi / 180])
+        pos, yaw, new_old, pd, ds, d = capi.vote_epilogue(pos0, e0, loc, gyr, old)
+        dx, dy = loc[0] - pos0[0], loc[1] - pos0[1]
+        want_pd = np.array([np.cos(-e0) * dx - np.sin(-e0) * dy, np.sin(-e0) * dx + np.cos(-e0) * dy,
+                            loc[2] - pos0[2]])
+        assert np.array_equal(pd, want_pd)
+        assert np.array_equal(pos, loc[:3]) and yaw == loc[3] and new_old == gyr
+        if abs(old - gyr) < pi:
+            dg = gyr - old
+        elif gyr < 0:
+            dg = 2 * pi + gyr - old
+        else:
+            dg = -2 * pi + gyr - old
+        assert ds == loc[3] - e0 and d == (dg + ds) / 2
+    p, q = capi.pose_message([1.0, 2.0, 3.0], 0.4)
+    assert np.array_equal(p, [1.0, -3.0, 2.0])
+    a = (-0.4 - pi / 2) / 2
+    assert np.array_equal(q, [np.cos(a), 0.0, np.sin(a), 0.0])

@@ -547,15 +547,26 @@ def test_sharded_backend_on_rccl_single_rank():
         sc = synth.scene(dims, P, M, seed=31)
         u = capi.draw_uniform(8, P)
         out = []
-        for sharded in (False, "torch", "native"):
+        # "native": both all-gathers as one RCCL group inside pf_weights; "native-two": one per call
+        # (SLAM_PF_TWO_GATHERS=1); "native-late": a predict between pf_weights and pf_resample, which
+        # must make pf_resample gather the new pose blocks itself
+        x2 = sc["x"] + 0.01
+        for sharded in (False, "torch", "native", "native-two", False, "native-late"):
+            late = sharded == "native-late" or (sharded is False and len(out) == 4)
+            if sharded == "native-two":
+                os.environ["SLAM_PF_TWO_GATHERS"] = "1"
             h = capi.Handle(_shared_cfg(P, dims))
-            be = ShardedBackend(h, dist, native=sharded == "native") if sharded else h
+            os.environ.pop("SLAM_PF_TWO_GATHERS", None)
+            native = str(sharded).startswith("native")
+            be = ShardedBackend(h, dist, native=native) if sharded else h
             if sharded:
-                assert be.native == (sharded == "native")
+                assert be.native == native
             try:
                 h.write_map(0, sc["grid"]); be.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
                 be.set_beams(*sc["beams"]); be.measure(0); be.weights()
                 w, lw = h.get_weights()
+                if late:
+                    be.predict(x2, sc["y"], sc["z"], sc["yaw"])
                 r = be.resample(u)
                 out.append((w, lw, r[0], r[1], np.stack(h.get_poses())))
                 if sharded:
@@ -563,9 +574,12 @@ def test_sharded_backend_on_rccl_single_rank():
                     assert bp == tuple(np.stack(h.get_poses())[:, r[1]])
             finally:
                 h.close()
-        for other in out[1:]:
+        for other in out[1:4]:
             for a, b in zip(out[0], other):
                 assert np.array_equal(a, b)
+        for a, b in zip(out[4], out[5]):
+            assert np.array_equal(a, b)
+        assert not np.array_equal(out[0][4], out[4][4])         # the late predict did change the poses
     finally:
         if created:
             dist.destroy_process_group()

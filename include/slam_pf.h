@@ -227,8 +227,8 @@ int pf_depth_to_cloud(pf_handle* h, const uint8_t* image, int32_t width, int32_t
                       double focal, double* cloud_out, int64_t capacity, int64_t* n_out);
 
 /* ---- map read-out for publishing: S3P:1031-1051 with reverse_index_conv_p S3P:100-110 ---------
- *  Every stride-th cell (S3P:1031: 4) of particle `particle`'s grid (global
- * index; 0 on a PF_MAP_SHARED handle) whose value is above threshold (S3P:1033: 80), in index
+ *  Every stride-th cell (S3P:1031: 4) of a grid (slab `particle` of the local
+ * shard, ignored on a PF_MAP_SHARED handle, like pf_read_map) above threshold (S3P:1033: 80), in index
  * order, as the float32 triples the reference puts into sensor_msgs/PointCloud: (X*res, -Z*res,
  * Y*res), the index split in the reference's double arithmetic. xyz_out: host float [capacity][3].
  * *n_out = triples written (<= capacity); *total_out (may be NULL) = cells that qualified. */
@@ -294,6 +294,18 @@ void pfh_vote_epilogue(double pos_scan[3], double* yaw_scan, const double loc[4]
  * (cos(a), 0, sin(a), 0) with a = (-yaw - pi/2)/2. */
 void pfh_pose_message(const double pos[3], double yaw, double position_out[3],
                       double orientation_wxyz_out[4]);
+/* S3P:805-812 across shards (per-particle maps on several GPUs; what pf_resample does inside when
+ * the handle has a communicator, exported for hosts that move the slabs themselves). slot_anc:
+ * the n_global ancestors pf_resample returned; shards of n_local slots. Every replaced slot whose
+ * ancestor lives on another rank is one transfer, numbered in slot order (the same number on
+ * every rank). Out, for `rank`: the slabs it sends (local index of the ancestor, destination rank,
+ * transfer number) and receives (local index of the slot, source rank, number), each in
+ * ascending number, at most cap entries written per list. Returns the number of transfers of the
+ * whole job. */
+int64_t pfh_migration_plan(const int32_t* slot_anc, int64_t n_global, int64_t n_local, int32_t rank,
+                           int32_t* send_src, int32_t* send_peer, int64_t* send_seq, int64_t* n_send,
+                           int32_t* recv_dst, int32_t* recv_peer, int64_t* recv_seq, int64_t* n_recv,
+                           int64_t cap);
 /* S3P:805-812 on the caller's own per-particle records. */
 void pfh_permute(int64_t n, const int32_t* slot_anc, void* records, size_t width);
 

@@ -27,7 +27,7 @@ SYMBOLS = (
     "pfh_snapshot_beams pfh_predict pfh_draw_noise pfh_draw_uniform pfh_add_points_policy "
     "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init "
     "pf_ring_default_params pf_ring_init pf_ring_paint pf_ring_update pf_ring_state "
-    "pf_depth_to_cloud pf_read_occupied pfh_draw_indices pfh_vote_epilogue pfh_pose_message").split()
+    "pf_depth_to_cloud pf_read_occupied pfh_draw_indices pfh_vote_epilogue pfh_pose_message pfh_migration_plan").split()
 
 
 class Config(C.Structure):
@@ -74,6 +74,7 @@ def lib():
             getattr(L, name).restype = C.c_void_p
             getattr(L, name).argtypes = [C.c_void_p]
         L.pfh_snapshot_beams.restype = C.c_int64
+        L.pfh_migration_plan.restype = C.c_int64
         L.pf_destroy.restype = None
         L.pf_destroy.argtypes = [C.c_void_p]
         _lib = L
@@ -428,6 +429,19 @@ def pose_message(pos, yaw):
     p = np.empty(3, np.float64); q = np.empty(4, np.float64)
     lib().pfh_pose_message(_p(pos), C.c_double(yaw), _p(p), _p(q))
     return p, q
+
+
+def migration_plan(slot_anc, n_local, rank):
+    """pfh_migration_plan: (total transfers, sends [(src_local, peer, seq)], recvs [(dst_local, peer, seq)])."""
+    sa = _c(slot_anc, np.int32)
+    cap = len(sa)
+    ss = np.empty(cap, np.int32); sp = np.empty(cap, np.int32); sq = np.empty(cap, np.int64)
+    rd = np.empty(cap, np.int32); rp = np.empty(cap, np.int32); rq = np.empty(cap, np.int64)
+    ns = C.c_int64(0); nr = C.c_int64(0)
+    total = lib().pfh_migration_plan(_p(sa), C.c_int64(cap), C.c_int64(n_local), C.c_int32(rank), _p(ss), _p(sp),
+                                     _p(sq), C.byref(ns), _p(rd), _p(rp), _p(rq), C.byref(nr), C.c_int64(cap))
+    return (total, list(zip(ss[:ns.value].tolist(), sp[:ns.value].tolist(), sq[:ns.value].tolist())),
+            list(zip(rd[:nr.value].tolist(), rp[:nr.value].tolist(), rq[:nr.value].tolist())))
 
 
 def comm_unique_id():

@@ -127,6 +127,9 @@ struct pf_handle {
     // there. A predict between the two calls clears the flag and pf_resample gathers itself.
     // SLAM_PF_TWO_GATHERS=1: always one collective per call, as before.
     bool poses_gathered = false;
+    int comm_rank = 0;
+    std::vector<int32_t> h_slots, mg_src, mg_speer, mg_dst, mg_rpeer;   // map migration (per-particle maps, sharded)
+    std::vector<int64_t> mg_sseq, mg_rseq;
     bool group_gathers = true;
     double* poses_all = nullptr;       // [world][9][P]
     // profiling
@@ -218,6 +221,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -238,6 +243,8 @@ Rccl& rccl() {
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    r.Send = (decltype(r.Send))dlsym(r.lib, "ncclSend");
+    r.Recv = (decltype(r.Recv))dlsym(r.lib, "ncclRecv");
     r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
@@ -350,10 +357,6 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
         return fail(nullptr, PF_ERR_ARG, "pf_create: local dims out of range");
     if (c.map_mode != PF_MAP_SHARED && c.map_mode != PF_MAP_PER_PARTICLE)
         return fail(nullptr, PF_ERR_ARG, "pf_create: map_mode");
-    if (c.map_mode == PF_MAP_PER_PARTICLE && c.n_particles_global != c.n_particles)
-        return fail(nullptr, PF_ERR_ARG,
-                    "pf_create: per-particle maps are single-handle for now (map migration "
-                    "between ranks is not implemented)");
     if (!(c.resolution > 0.0) || c.max_beams < 1 || c.max_points < 0 || c.map_lo < 0 ||
         c.map_hi > 255 || c.map_lo > c.map_hi || c.map_prior < 0 || c.map_prior > 255)
         return fail(nullptr, PF_ERR_ARG, "pf_create: resolution/capacities/clamps");
@@ -812,6 +815,10 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
     if (!u && !h->have_u) return fail(h, PF_ERR_ARG, "pf_resample: no thresholds resident");
     if (h->Pg != h->P && !poses_global_dev && !h->comm)
         return fail(h, PF_ERR_ARG, "pf_resample: sharded handle needs the gathered pose blocks (or pf_comm_init)");
+    const bool migrate = h->slab && h->Pg != h->P;
+    if (migrate && !(h->comm && rccl().Send && rccl().Recv && rccl().GroupStart && rccl().GroupEnd))
+        return fail(h, PF_ERR_ARG, "pf_resample: per-particle maps on a sharded handle move between ranks "
+                                   "inside the library: pf_comm_init first");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (!poses_global_dev && h->comm) {               // C2: the 72-B pose blocks, rank order
         if (!h->poses_gathered) {                     // (else pf_weights' group already brought them)
@@ -849,6 +856,46 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
     if (slot_anc_out)
         HIP_TRY(h, hipMemcpyAsync(slot_anc_out, h->slot_anc, sizeof(int32_t) * (size_t)h->Pg,
                                   hipMemcpyDeviceToHost, h->stream));
+    if (migrate) {
+        // S3P:810 across ranks: the slabs whose ancestor lives on another GPU (local ones were
+        // copied by the kernels above). Sources are surviving slots and destinations never-drawn
+        // ones, so no transfer reads what another writes.
+        const size_t Pg = (size_t)h->Pg;
+        h->h_slots.resize(Pg);
+        for (auto* v : {&h->mg_src, &h->mg_speer, &h->mg_dst, &h->mg_rpeer}) v->resize(Pg);
+        h->mg_sseq.resize(Pg); h->mg_rseq.resize(Pg);
+        HIP_TRY(h, hipMemcpyAsync(h->h_slots.data(), h->slot_anc, sizeof(int32_t) * Pg, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        int64_t ns = 0, nr = 0;
+        pfh_migration_plan(h->h_slots.data(), h->Pg, h->P, h->comm_rank, h->mg_src.data(), h->mg_speer.data(),
+                           h->mg_sseq.data(), &ns, h->mg_dst.data(), h->mg_rpeer.data(), h->mg_rseq.data(), &nr,
+                           (int64_t)Pg);
+        // one RCCL group per PF_MIGRATE_GROUP transfer numbers: the same cut on every rank
+        const int64_t kGroup = 512;
+        int64_t is = 0, ir = 0;
+        while (is < ns || ir < nr) {
+            const int64_t next = is < ns && (ir >= nr || h->mg_sseq[(size_t)is] < h->mg_rseq[(size_t)ir])
+                                     ? h->mg_sseq[(size_t)is] : h->mg_rseq[(size_t)ir];
+            const int64_t end = (next / kGroup + 1) * kGroup;
+            ncclResult_t r = rccl().GroupStart();
+            while (r == ncclSuccess && (is < ns || ir < nr)) {
+                const bool s_ok = is < ns && h->mg_sseq[(size_t)is] < end, r_ok = ir < nr && h->mg_rseq[(size_t)ir] < end;
+                if (!s_ok && !r_ok) break;
+                if (s_ok && (!r_ok || h->mg_sseq[(size_t)is] < h->mg_rseq[(size_t)ir])) {
+                    r = rccl().Send(h->maps + h->slab * (unsigned long long)h->mg_src[(size_t)is], (size_t)h->elements,
+                                    ncclUint8, h->mg_speer[(size_t)is], h->comm, h->stream);
+                    ++is;
+                } else {
+                    r = rccl().Recv(h->maps + h->slab * (unsigned long long)h->mg_dst[(size_t)ir], (size_t)h->elements,
+                                    ncclUint8, h->mg_rpeer[(size_t)ir], h->comm, h->stream);
+                    ++ir;
+                }
+            }
+            const ncclResult_t e = rccl().GroupEnd();
+            if (r == ncclSuccess) r = e;
+            if (r != ncclSuccess) return fail(h, PF_ERR_HIP, "pf_resample: map migration: %s", rccl().GetErrorString(r));
+        }
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     cnt[0] = h->h_result[0]; cnt[1] = h->h_result[1]; cnt[2] = h->h_result[2];
     if (best_out) *best_out = (int32_t)(h->h_result[3] & 0xffffffffull);
@@ -1060,10 +1107,9 @@ int pf_read_occupied(pf_handle* h, int32_t particle, int32_t threshold, int32_t 
     NEED(h, stride >= 1, "stride");
     NEED(h, capacity <= (int64_t)1 << 28, "capacity beyond 2^28 points");
     const uint8_t* grid = h->maps;
-    if (h->cfg.map_mode == PF_MAP_SHARED) NEED(h, particle == 0, "a PF_MAP_SHARED handle has one grid: particle must be 0");
-    else {
-        NEED(h, particle >= h->offset && particle < h->offset + h->P, "particle is not on this handle");
-        grid += h->slab * (unsigned long long)(particle - h->offset);
+    if (h->slab) {                                    // like pf_read_map: slab i of the local shard
+        NEED(h, particle >= 0 && particle < h->P, "particle index");
+        grid += h->slab * (unsigned long long)particle;
     }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, wait_map_writes(h));
@@ -1287,7 +1333,6 @@ int pf_comm_init(pf_handle* h, const void* id, int32_t rank, int32_t world) {
     NEED(h, id && world >= 1 && rank >= 0 && rank < world, "id / rank / world");
     NEED(h, (long long)h->P * world == h->Pg && h->offset == rank * h->P,
          "shards must be equal contiguous blocks: n_particles * world == n_particles_global, particle_offset == rank * n_particles");
-    NEED(h, h->cfg.map_mode == PF_MAP_SHARED || world == 1, "per-particle maps are single-handle");
     NEED(h, !h->comm, "communicator already set");
     if (!rccl().ok) return fail(h, PF_ERR_NODEVICE, "pf_comm_init: librccl not loadable");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -1299,6 +1344,7 @@ int pf_comm_init(pf_handle* h, const void* id, int32_t rank, int32_t world) {
         return fail(h, PF_ERR_HIP, "ncclCommInitRank: %s", rccl().GetErrorString(r));
     }
     h->comm_world = world;
+    h->comm_rank = rank;
     HIP_TRY(h, dalloc(&h->scores_all, (size_t)h->Pg));
     HIP_TRY(h, dalloc(&h->poses_all, PF_POSE_ROWS * (size_t)h->Pg));
     return PF_OK;

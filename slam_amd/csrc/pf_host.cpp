@@ -126,6 +126,33 @@ void pfh_pose_message(const double pos[3], double yaw, double position_out[3], d
     position_out[2] = pos[1];
 }
 
+int64_t pfh_migration_plan(const int32_t* slot_anc, int64_t n_global, int64_t n_local, int32_t rank,
+                           int32_t* send_src, int32_t* send_peer, int64_t* send_seq, int64_t* n_send,
+                           int32_t* recv_dst, int32_t* recv_peer, int64_t* recv_seq, int64_t* n_recv,
+                           int64_t cap) {
+    // S3P:805-812 across shards: slot g takes its ancestor's map; when the ancestor lives on another
+    // rank the slab crosses the link. Every rank walks the same slot_anc[] in the same order, so the
+    // sequence numbers agree everywhere and sends meet their receives in order per pair of ranks.
+    int64_t seq = 0, ns = 0, nr = 0;
+    for (int64_t g = 0; g < n_global; ++g) {
+        const int64_t a = slot_anc[g];
+        if (a == g) continue;
+        const int64_t rg = g / n_local, ra = a / n_local;
+        if (rg == ra) continue;
+        if (ra == rank) {
+            if (ns < cap) { send_src[ns] = (int32_t)(a - ra * n_local); send_peer[ns] = (int32_t)rg; send_seq[ns] = seq; }
+            ++ns;
+        }
+        if (rg == rank) {
+            if (nr < cap) { recv_dst[nr] = (int32_t)(g - rg * n_local); recv_peer[nr] = (int32_t)ra; recv_seq[nr] = seq; }
+            ++nr;
+        }
+        ++seq;
+    }
+    *n_send = ns; *n_recv = nr;
+    return seq;
+}
+
 void pfh_permute(int64_t n, const int32_t* slot_anc, void* records, size_t width) {
     char* r = (char*)records;                              // S3P:805-812
     for (int64_t i = 0; i < n; ++i)

@@ -790,6 +790,7 @@ __global__ __launch_bounds__(NB) void k_apply_maps(const int32_t* __restrict__ s
     const int i = blockIdx.x;
     const int a = slot_anc[offset + i];
     if (a == offset + i) return;
+    if (a < offset || a >= offset + P) return;               // another rank's slab: pf_resample receives it
     const uint4* src = (const uint4*)(maps + stride * (unsigned long long)(a - offset));
     uint4* dst = (uint4*)(maps + stride * (unsigned long long)i);
     const unsigned long long n16 = (bytes + 15) / 16;        // slabs are padded to 256 B

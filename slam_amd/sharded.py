@@ -11,6 +11,9 @@ Per step and rank:
   resample  redundantly on every rank; slot numbering is global, so slot_anc[] is identical to
             the one-GPU run.
 The shared grid is replicated; every rank applies the identical update_map.
+Per-particle maps (FastSLAM mode) live with their particle: pf_resample copies the slabs whose
+ancestor is on the same rank and moves the others with RCCL send/receive groups itself, which
+needs the library's own communicator (native=True on the nccl backend).
 """
 import numpy as np
 

@@ -192,3 +192,43 @@ def test_vote_epilogue_and_pose_message_follow_the_reference_formulas():
     assert np.array_equal(p, [1.0, -3.0, 2.0])
     a = (-0.4 - pi / 2) / 2
     assert np.array_equal(q, [np.cos(a), 0.0, np.sin(a), 0.0])
+
+
+@pytest.mark.parametrize("world,P", [(2, 50), (4, 33), (8, 125)])
+def test_migration_plan_moves_every_remote_ancestor(world, P):
+    """pfh_migration_plan (S3P:805-812 across shards): each rank's send and receive lists, played
+    through per-pair FIFO channels the way RCCL matches sends and receives of one pair of ranks,
+    must leave every slot with its ancestor's slab; transfer numbers agree on both ends."""
+    rng = np.random.default_rng(world * 1000 + P)
+    Pg = world * P
+    w = rng.random(Pg) ** 6 + 1e-9
+    w /= w.sum()
+    _, slot_anc, _, _ = O.resample(w, rng.random(Pg), 0)
+    slot_anc = np.asarray(slot_anc, np.int32)
+    assert np.array_equal(slot_anc[slot_anc], slot_anc)          # sources are surviving slots
+    slabs = [np.arange(r * P, (r + 1) * P) for r in range(world)]   # slab tag = its first owner
+    plans = [capi.migration_plan(slot_anc, P, r) for r in range(world)]
+    totals = {p[0] for p in plans}
+    assert len(totals) == 1
+    remote = sum(1 for g in range(Pg) if slot_anc[g] != g and slot_anc[g] // P != g // P)
+    assert totals.pop() == remote and remote > 0
+    new = [s.copy() for s in slabs]
+    for r in range(world):                                       # local copies (k_apply_maps)
+        for i in range(P):
+            a = int(slot_anc[r * P + i])
+            if a // P == r:
+                new[r][i] = slabs[r][a - r * P]
+    chan = {}
+    for r, (_, sends, _) in enumerate(plans):
+        assert [q for _, _, q in sends] == sorted(q for _, _, q in sends)
+        for src, peer, seq in sends:
+            assert peer != r
+            chan.setdefault((r, peer), []).append((slabs[r][src], seq))
+    for r, (_, _, recvs) in enumerate(plans):
+        assert [q for _, _, q in recvs] == sorted(q for _, _, q in recvs)
+        for dst, peer, seq in recvs:
+            tag, sseq = chan[(peer, r)].pop(0)
+            assert sseq == seq
+            new[r][dst] = tag
+    assert all(len(v) == 0 for v in chan.values())
+    assert np.array_equal(np.concatenate(new), slot_anc)

@@ -792,7 +792,7 @@ def test_map_read_out_matches_oracle(dims, stride):
         none, _ = h.read_occupied(0, 255, stride)
         assert none.shape == (0, 3)
         with pytest.raises(capi.PfError):
-            h.read_occupied(1, 80, stride)
+            h.read_occupied(0, 80, 0)
     finally:
         h.close()
     if dims[0] > 40:
@@ -808,5 +808,36 @@ def test_map_read_out_matches_oracle(dims, stride):
         for i in range(P):
             got, _ = h.read_occupied(i, 80, stride)
             assert np.array_equal(got, O.read_occupied(grids[i], 0.05, 80, stride))
+        with pytest.raises(capi.PfError):
+            h.read_occupied(P, 80, stride)
+    finally:
+        h.close()
+
+
+def test_sharded_per_particle_maps_need_the_library_communicator():
+    """Per-particle maps on a shard of a larger job (FastSLAM mode): the slabs of remote
+    ancestors cross ranks inside pf_resample (RCCL send/receive; the plan is tested on the CPU by
+    tests/test_capi_cpu.py::test_migration_plan_moves_every_remote_ancestor, the transfers
+    themselves need more than the one GPU of this box). Without pf_comm_init the call must fail
+    with a clear message instead of leaving remote slots stale; measure, weights and every local
+    accessor work on such a handle."""
+    import torch
+    P, world, dims = 64, 2, (24, 24, 16)
+    sc = synth.scene(dims, P, 40, seed=5)
+    cfg = capi.default_config(n_particles=P, n_particles_global=P * world, particle_offset=P,
+                              map_mode=capi.PF_MAP_PER_PARTICLE, grid_x=dims[0], grid_y=dims[1],
+                              grid_z=dims[2], max_beams=64, max_points=64)
+    h = capi.Handle(cfg)
+    try:
+        h.broadcast_map(sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+        h.set_beams(*sc["beams"]); h.measure(1)
+        s, c = h.get_scores()
+        scores = torch.tensor(np.stack([np.concatenate([s, s]), np.concatenate([c, c])], 1).astype(np.int32),
+                              device="cuda")
+        h.weights(scores.data_ptr())
+        poses = h.poses_tensor()
+        both = torch.cat([poses, poses], 0).contiguous()
+        with pytest.raises(capi.PfError, match="pf_comm_init"):
+            h.resample(capi.draw_uniform(3, P * world), both.data_ptr(), True)
     finally:
         h.close()

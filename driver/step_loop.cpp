@@ -1,101 +1,184 @@
 // Plain C++ host driver: the stand-in for the reference's main() + Slam::callback() loop
 // (S3P:1080-1118, S3P:168-205) without ROS. It keeps exactly what the reference keeps on the
-// host — the local-map snapshot under a mutex, the motion model with its std::mt19937 noise,
-// the add_points policy, the correction feedback — and reaches the GPU through the C ABI of
-// include/slam_pf.h in the reference's per-step order. Synthetic room, synthetic depth scans.
+// host — the member state of class Slam, the local-map snapshot under a mutex, the motion model
+// with its std::mt19937 noise, the add_points policy, the correction feedback — and reaches the
+// GPU through the C ABI of include/slam_pf.h in the reference's order:
 //
-//   ./step_loop [steps] [particles]        (needs an MI355X; the library has no CPU path)
+//   per depth frame (callback(), S3P:168-205)
+//     pf_depth_to_cloud                  resize_depth_to_array + img_to_cloud   S3P:574-611
+//     pf_ring_paint, pf_scan_vote        scan_localization                      S3P:300-376
+//     pfh_vote_hypothesis / _epilogue                                           S3P:366-404
+//     pf_ring_update                     scan_localization_map_update           S3P:419-529
+//     pf_set_scan, pf_update_map         build_local_map                        S3P:621-710
+//     pfh_pose_message                   pub_pose_func                          S3P:207-222
+//   per filter step (particle_map(), S3P:827-962)
+//     pf_read_local_map ... pf_resample
+//   at the end (publish_cloud, S3P:1031-1051)
+//     pf_read_occupied
+//
+// Synthetic box room, synthetic 640x480 uint16 depth frames of it. Two handles: the filter
+// (per-particle maps, the reference's sizes) and the localisation grid (200x200x80, shared).
+//
+//   ./step_loop [steps] [particles] [truth]     (needs an MI355X; the library has no CPU path)
+//   "truth": feed the true increment as odometry instead of the scan vote (the first form of
+//   this driver; keeps the filter's input independent of the front end)
 #include "../include/slam_pf.h"
 
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <random>
 #include <vector>
 
-#define CK(call)                                                                        \
+#define CK(hh, call)                                                                    \
     do {                                                                                \
         int rc_ = (call);                                                               \
         if (rc_ != PF_OK) {                                                             \
-            std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, pf_last_error(h));       \
+            std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, pf_last_error(hh));      \
             return 1;                                                                   \
         }                                                                               \
     } while (0)
 
 namespace {
-const double kRes = 0.05;
 std::mutex mtx;                                  // S3P:27
+const int kW = 640, kH = 480, kPool = 4;         // S3P:113-117
+const double kFocal = 385.0 / 4.0;               // S3P:124
 
-// a box room (walls at +-2.5 m around the start pose, floor/ceiling) as a depth "scan": points
-// in the sensor frame for a sensor at world pose (x, y, z, yaw)
-std::vector<double> synth_scan(double x, double y, double z, double yaw, int n, std::mt19937& g) {
-    std::uniform_real_distribution<double> az(-0.6, 0.6), el(-0.45, 0.45);
-    std::vector<double> pts;
-    pts.reserve(3 * (size_t)n);
-    const double x0 = 5.0, x1 = 10.0, y0 = 5.0, y1 = 10.0, z0 = 0.3, z1 = 3.2;
-    for (int i = 0; i < n; ++i) {
-        const double a = az(g), e = el(g);
-        // sensor looks along +y (the reference's depth axis, S3P:115)
-        const double dx = std::sin(a) * std::cos(e), dy = std::cos(a) * std::cos(e), dz = std::sin(e);
-        const double wx = std::cos(yaw) * dx - std::sin(yaw) * dy, wy = std::sin(yaw) * dx + std::cos(yaw) * dy;
-        double t = 1e9;
-        if (wx > 0) t = std::fmin(t, (x1 - x) / wx); else if (wx < 0) t = std::fmin(t, (x0 - x) / wx);
-        if (wy > 0) t = std::fmin(t, (y1 - y) / wy); else if (wy < 0) t = std::fmin(t, (y0 - y) / wy);
-        if (dz > 0) t = std::fmin(t, (z1 - z) / dz); else if (dz < 0) t = std::fmin(t, (z0 - z) / dz);
-        if (t > 8.0) continue;
-        pts.push_back(dx * t); pts.push_back(dy * t); pts.push_back(dz * t);
-    }
-    return pts;
+// One depth frame of a box room seen from (x, y, z, yaw) in the room's frame: the camera looks
+// along +y of its own frame (S3P:115), pixel (i, j) of the pooled image has the direction
+// (horizontal[j], 1, vertical[i]) of the reference's pinhole tables (S3P:155-162); each pooled
+// depth is written to its 4x4 block of uint16 millimetres, little-endian (S3P:587).
+void synth_depth(double x, double y, double z, double yaw, std::vector<uint8_t>& img) {
+    const double x0 = 2.0, x1 = 8.0, y0 = 2.0, y1 = 8.0, z0 = 0.8, z1 = 3.2;
+    const int rh = kW / kPool, rv = kH / kPool;
+    img.assign((size_t)kW * kH * 2, 0);
+    for (int i = 0; i < rv; ++i)
+        for (int j = 0; j < rh; ++j) {
+            const double hx = ((j + 1) - rh / 2) / kFocal, vz = -1 * ((i + 1) - rv / 2) / kFocal;
+            const double wx = std::cos(yaw) * hx - std::sin(yaw), wy = std::sin(yaw) * hx + std::cos(yaw);
+            double t = 1e9;
+            if (wx > 0) t = std::fmin(t, (x1 - x) / wx); else if (wx < 0) t = std::fmin(t, (x0 - x) / wx);
+            if (wy > 0) t = std::fmin(t, (y1 - y) / wy); else if (wy < 0) t = std::fmin(t, (y0 - y) / wy);
+            if (vz > 0) t = std::fmin(t, (z1 - z) / vz); else if (vz < 0) t = std::fmin(t, (z0 - z) / vz);
+            const long mm = std::lround(t * 1000.0);
+            if (mm <= 0 || mm > 6000) continue;                  // out of the sensor's range: no depth
+            for (int a = 0; a < kPool; ++a)
+                for (int b = 0; b < kPool; ++b) {
+                    const size_t k = ((size_t)(i * kPool + a) * kW + (size_t)j * kPool + b) * 2;
+                    img[k] = (uint8_t)(mm & 0xff); img[k + 1] = (uint8_t)(mm >> 8);
+                }
+        }
 }
 }  // namespace
 
 int main(int argc, char** argv) {
     const int steps = argc > 1 ? std::atoi(argv[1]) : 20;
     const int P = argc > 2 ? std::atoi(argv[2]) : 50;
+    const bool truth_odometry = argc > 3 && std::strcmp(argv[3], "truth") == 0;
+    const double pi = 2 * std::acos(0.0);
+
+    // ---- the filter: S3P:23-69 ----
     pf_config cfg;
-    pf_default_config(&cfg);                     // S3P:23-69
+    pf_default_config(&cfg);
     cfg.n_particles = cfg.n_particles_global = P;
     pf_handle* h = nullptr;
     if (pf_create(&cfg, &h) != PF_OK) {
         std::fprintf(stderr, "pf_create: %s\n", pf_last_error(nullptr));
         return 1;
     }
+    // ---- the localisation grid and its keyframe ring: S3P:64, 286-289 ----
+    pf_config lcfg;
+    pf_default_config(&lcfg);
+    lcfg.n_particles = lcfg.n_particles_global = 1;
+    lcfg.map_mode = PF_MAP_SHARED;
+    lcfg.grid_x = 200; lcfg.grid_y = 200; lcfg.grid_z = 80;
+    lcfg.local_x = lcfg.local_y = lcfg.local_z = 0;
+    lcfg.max_beams = 64;
+    pf_handle* loc = nullptr;
+    if (pf_create(&lcfg, &loc) != PF_OK) {
+        std::fprintf(stderr, "pf_create (localisation grid): %s\n", pf_last_error(nullptr));
+        return 1;
+    }
+    CK(loc, pf_fill_maps(loc, 0));
+    pf_ring_params rp;
+    pf_ring_default_params(&rp);
+    CK(loc, pf_ring_init(loc, &rp));
+
     const int L = cfg.local_x * cfg.local_y * cfg.local_z;
+    const int npix = (kW / kPool) * (kH / kPool);
     std::vector<int8_t> local((size_t)L);
     std::vector<int32_t> bx((size_t)L), by((size_t)L), bz((size_t)L), slots((size_t)P);
     std::vector<int8_t> bv((size_t)L);
     std::vector<double> x((size_t)P, 7.5), y((size_t)P, 7.5), z((size_t)P, 1.5), yaw((size_t)P, 0.0), u((size_t)P);
     std::vector<float> noise(4 * (size_t)P);
-    // host state of the reference (S3P:56-61, 823-825)
+    std::vector<uint8_t> img;
+    std::vector<double> cloud(3 * (size_t)npix), sample(3 * 500);
+    std::vector<int32_t> pick(500), ray_idx(2400);
+    // members of class Slam (S3P:56-61, 265-283, 823-825)
     double local_pos[3] = {5, 5, 1.5}, local_yaw = 0;
     double pos[4] = {7.5, 7.5, 1.5, 0}, last_update[4] = {7.5, 7.5, 1.5, 0}, diff[4] = {0, 0, 0, 0};
+    double pos_scan[3] = {5, 5, 2}, yaw_scan = 0, vote_loc[4] = {5, 5, 2, 0};
+    double gyr_yaw_old = 0, yaw_diff_scan = 0;
     int add_points = 1, best = 0;
-    double truth[4] = {7.5, 7.5, 1.5, 0};
-    std::mt19937 scan_rng(1), ray_rng(4);
+    double truth[4] = {5, 5, 2, 0};               // the sensor in the room's frame = the localisation frame
     std::random_device rd;
     const pf_update_params upd = {10, 50, -3, -50, 3.0};   // S3P:637, 650-655, 695-700
     const int frames_per_step = 8;
+    long votes = 0, no_votes = 0, keyframes = 0;
 
     for (int t = 0; t < steps; ++t) {
-        // ---- camera callback side (S3P:168-205), `frames_per_step` depth frames ----
+        // ---- camera callback (S3P:168-205), `frames_per_step` depth frames ----
         for (int f = 0; f < frames_per_step; ++f) {
-            const double d[4] = {0.012 * std::cos(truth[3]), 0.012 * std::sin(truth[3]), 0.0, 0.004};
+            const double d[4] = {-0.012 * std::sin(truth[3]), 0.012 * std::cos(truth[3]), 0.0, 0.004};
             for (int k = 0; k < 4; ++k) truth[k] += d[k];
-            std::vector<double> pts = synth_scan(truth[0], truth[1], truth[2], truth[3], 4000, scan_rng);
-            const int n = (int)pts.size() / 3;
-            std::vector<int32_t> ray_idx(2400);
-            std::uniform_int_distribution<> pick(0, n > 0 ? n - 1 : 0);
-            for (auto& r : ray_idx) r = pick(ray_rng);     // S3P:666-669 (host-drawn)
-            std::lock_guard<std::mutex> lk(mtx);           // S3P:622
-            // odometry stand-in: the true increment in the local frame (S3P:623-626)
-            local_pos[0] += std::cos(-pos[3]) * d[0] - std::sin(-pos[3]) * d[1];
-            local_pos[1] += std::sin(-pos[3]) * d[0] + std::cos(-pos[3]) * d[1];
-            local_pos[2] += d[2]; local_yaw += d[3];
-            const double zyx[3] = {local_yaw, 0.0, 0.0};
-            CK(pf_set_scan(h, pts.data(), n, ray_idx.data(), n > 0 ? (int64_t)ray_idx.size() : 0));
-            CK(pf_update_map(h, PF_GRID_LOCAL, &upd, local_pos, zyx));   // S3P:628-704
-            for (int k = 0; k < 4; ++k) pos[k] += d[k] + diff[k];        // S3P:712-716
+            synth_depth(truth[0], truth[1], truth[2], truth[3], img);
+            int64_t n = 0;
+            CK(loc, pf_depth_to_cloud(loc, img.data(), kW, kH, kPool, kFocal, cloud.data(), npix, &n));   // S3P:173-175
+            double pos_diff_scan[3] = {0, 0, 0}, yaw_diff = 0;
+            const double zyx[3] = {yaw_scan, 0.0, 0.0};          // no IMU here: rot_y = rot_x = 0 (S3P:301-302)
+            if (truth_odometry) {
+                pos_diff_scan[0] = std::cos(-truth[3] + d[3]) * d[0] - std::sin(-truth[3] + d[3]) * d[1];
+                pos_diff_scan[1] = std::sin(-truth[3] + d[3]) * d[0] + std::cos(-truth[3] + d[3]) * d[1];
+                pos_diff_scan[2] = d[2]; yaw_diff = d[3];
+            } else if (n > 0) {
+                // scan_localization(): S3P:300-410
+                const double gyr_yaw = pos[3] + yaw_diff_scan;   // S3P:184 (no gyro message)
+                CK(loc, pf_ring_paint(loc));                                                    // S3P:305-312
+                pfh_draw_indices(rd(), 500, (int32_t)(n - 1), pick.data());                    // S3P:315-319
+                for (int k = 0; k < 500; ++k)
+                    for (int c = 0; c < 3; ++c) sample[3 * (size_t)k + c] = cloud[3 * (size_t)pick[(size_t)k] + c];
+                int64_t hyp = -1;
+                CK(loc, pf_scan_vote(loc, sample.data(), 500, pos_scan, zyx, 5, -6, 3, 5, 0.25, nullptr, &hyp));
+                double out[4];
+                if (pfh_vote_hypothesis(hyp, pos_scan, zyx, 0.05, 5, -6, 3, 5, 0.25, out) == 0) {
+                    std::memcpy(vote_loc, out, sizeof out);      // S3P:366-371; kept on "no vote"
+                    ++votes;
+                } else {
+                    ++no_votes;
+                }
+                pfh_vote_epilogue(pos_scan, &yaw_scan, vote_loc, gyr_yaw, &gyr_yaw_old, pos_diff_scan,
+                                  &yaw_diff_scan, &yaw_diff);                                   // S3P:379-404
+                int32_t flags = 0;
+                const double zyx_now[3] = {yaw_scan, 0.0, 0.0};
+                CK(loc, pf_ring_update(loc, cloud.data(), n, pos_scan, zyx_now, &flags));       // S3P:419-529
+                keyframes += flags & 1;
+                if (flags & 2) { vote_loc[0] = pos_scan[0]; vote_loc[1] = pos_scan[1]; vote_loc[2] = pos_scan[2]; }
+            }
+            // build_local_map(): S3P:621-710
+            pfh_draw_indices(rd(), (int64_t)ray_idx.size(), (int32_t)(n > 0 ? n - 1 : 0), ray_idx.data());   // S3P:666-669
+            std::lock_guard<std::mutex> lk(mtx);                 // S3P:622
+            for (int k = 0; k < 3; ++k) local_pos[k] += pos_diff_scan[k];                       // S3P:623-626
+            local_yaw += yaw_diff;
+            const double lzyx[3] = {local_yaw, 0.0, 0.0};
+            CK(h, pf_set_scan(h, cloud.data(), n, ray_idx.data(), n > 0 ? (int64_t)ray_idx.size() : 0));
+            CK(h, pf_update_map(h, PF_GRID_LOCAL, &upd, local_pos, lzyx));                      // S3P:628-704
+            pos[0] += std::cos(pos[3]) * pos_diff_scan[0] - std::sin(pos[3]) * pos_diff_scan[1] + diff[0];   // S3P:712-716
+            pos[1] += std::sin(pos[3]) * pos_diff_scan[0] + std::cos(pos[3]) * pos_diff_scan[1] + diff[1];
+            pos[2] += pos_diff_scan[2] + diff[2];
+            pos[3] += yaw_diff + diff[3];
+            if (pos[3] > pi) pos[3] -= 2 * pi; else if (pos[3] < -pi) pos[3] += 2 * pi;
             for (double& v : diff) v = 0;
         }
         // ---- particle_map() (S3P:827-962) ----
@@ -103,34 +186,44 @@ int main(int argc, char** argv) {
         int64_t nb;
         {
             std::lock_guard<std::mutex> lk(mtx);           // S3P:833-846
-            CK(pf_read_local_map(h, local.data()));
+            CK(h, pf_read_local_map(h, local.data()));
             for (int k = 0; k < 3; ++k) p_local[k] = local_pos[k];
             p_local[3] = local_yaw;
             for (int k = 0; k < 4; ++k) p_pos[k] = pos[k];
-            CK(pf_reset_local_map(h));
+            CK(h, pf_reset_local_map(h));
             local_pos[0] = 5; local_pos[1] = 5; local_pos[2] = 1.5; local_yaw = 0;
         }
         nb = pfh_snapshot_beams(local.data(), cfg.local_x, cfg.local_y, cfg.local_z, 100, 100, 30,
                                 bx.data(), by.data(), bz.data(), bv.data(), (int64_t)L);   // S3P:868-877
         if (nb > cfg.max_beams) nb = cfg.max_beams;
-        CK(pf_set_beams(h, bx.data(), by.data(), bz.data(), bv.data(), nb));
-        CK(pf_measure(h, add_points));                                             // S3P:859-908
-        pfh_draw_noise(rd(), P, 0.03f, 0.02f, noise.data());                       // S3P:852-855
+        CK(h, pf_set_beams(h, bx.data(), by.data(), bz.data(), bv.data(), nb));
+        CK(h, pf_measure(h, add_points));                                             // S3P:859-908
+        pfh_draw_noise(rd(), P, 0.03f, 0.02f, noise.data());                          // S3P:852-855
         pfh_predict(P, x.data(), y.data(), z.data(), yaw.data(), p_local[0] - 5, p_local[1] - 5,
-                    p_local[2] - 1.5, p_local[3], noise.data());                   // S3P:911-914
-        CK(pf_predict(h, x.data(), y.data(), z.data(), yaw.data()));
-        CK(pf_weights(h, nullptr));                                                // S3P:920-937
-        add_points = pfh_add_points_policy(p_pos, last_update, 0.4);               // S3P:941-953
-        pfh_draw_uniform(rd(), P, u.data());                                       // S3P:768-773
+                    p_local[2] - 1.5, p_local[3], noise.data());                      // S3P:911-914
+        CK(h, pf_predict(h, x.data(), y.data(), z.data(), yaw.data()));
+        CK(h, pf_weights(h, nullptr));                                                // S3P:920-937
+        add_points = pfh_add_points_policy(p_pos, last_update, 0.4);                  // S3P:941-953
+        pfh_draw_uniform(rd(), P, u.data());                                          // S3P:768-773
         int64_t nohit = 0, amb = 0;
-        CK(pf_resample(h, u.data(), nullptr, slots.data(), &best, &nohit, &amb));  // S3P:954
+        CK(h, pf_resample(h, u.data(), nullptr, slots.data(), &best, &nohit, &amb));  // S3P:954
         for (auto* v : {&x, &y, &z, &yaw}) pfh_permute(P, slots.data(), v->data(), sizeof(double));
         diff[0] = x[(size_t)best] - p_pos[0]; diff[1] = y[(size_t)best] - p_pos[1];  // S3P:956-959
         diff[2] = z[(size_t)best] - p_pos[2]; diff[3] = yaw[(size_t)best] - p_pos[3];
-        std::printf("step %3d beams %6lld best %4d pose %.3f %.3f %.3f %.3f  truth %.3f %.3f %.3f %.3f  add %d\n",
+        double msg_pos[3], msg_q[4];
+        pfh_pose_message(pos, pos[3], msg_pos, msg_q);                                // S3P:207-222
+        // the filter's frame starts at (7.5, 7.5, 1.5), the room's at (5, 5, 2)
+        std::printf("step %3d beams %6lld best %4d pose %.3f %.3f %.3f %.3f  truth %.3f %.3f %.3f %.3f  add %d  msg (%.2f %.2f %.2f)\n",
                     t, (long long)nb, best, x[(size_t)best], y[(size_t)best], z[(size_t)best], yaw[(size_t)best],
-                    truth[0], truth[1], truth[2], truth[3], add_points);
+                    truth[0] + 2.5, truth[1] + 2.5, truth[2] - 0.5, truth[3], add_points, msg_pos[0], msg_pos[1], msg_pos[2]);
     }
+    // ---- publish_cloud (S3P:1031-1051): the best particle's occupied cells ----
+    std::vector<float> occ(3 * (size_t)(1 << 20));
+    int64_t n_occ = 0, total_occ = 0;
+    CK(h, pf_read_occupied(h, best, 80, 4, occ.data(), 1 << 20, &n_occ, &total_occ));
+    std::printf("front end: %ld votes, %ld frames without a vote, %ld keyframes; published cloud: %lld points\n",
+                votes, no_votes, keyframes, (long long)total_occ);
+    pf_destroy(loc);
     pf_destroy(h);
     return 0;
 }

@@ -442,6 +442,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     if (const char* e = getenv("SLAM_PF_SIDE")) h->use_side = atoi(e) != 0;
     if (const char* e = getenv("SLAM_PF_TWO_GATHERS")) h->group_gathers = atoi(e) == 0;
     if (const char* e = getenv("SLAM_PF_CHUNKS")) h->tune_chunks = atoi(e);
+    if (h->tune_chunks > h->max_chunks) h->max_chunks = h->tune_chunks < 1024 ? h->tune_chunks : 1024;
     if (const char* e = getenv("SLAM_PF_EXACT_MEASURE")) h->force_exact_measure = atoi(e);
     CREATE_TRY(dalloc(&h->partial, (size_t)h->max_chunks * P));
     CREATE_TRY(dalloc(&h->scores, P));

@@ -250,7 +250,7 @@ def main():
                        "grid": list(dims), "order": "fast" if Pg > 2048 else "exact",
                        "collectives": ("rccl in-library" if getattr(be, "native", False) else "torch.distributed nccl") if sharded else "none",
                        "ambiguous_draws": int(amb_total), "nohit_draws": int(nohit_total)},
-            "roofline": {"bound": "hbm", "kernel": "k_measure_swz", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_measure_col", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": k1_traffic(P, M, a.grid), "algorithmic_bytes_per_launch": k1_bytes,
                          "avg_launch_us": k1_avg_s * 1e6, "launches": int(k1_n),

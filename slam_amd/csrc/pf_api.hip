@@ -12,6 +12,7 @@
 #include <string.h>
 #include <new>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -48,7 +49,10 @@ struct pf_handle {
     PfBeam* beams = nullptr;           // [max_beams] every beam (fuse path, voxel indices)
     PfBeam* beams_occ = nullptr;       // [max_beams] occupied beams only (fast measure path)
     PfBeamF* beams_occ_f = nullptr;    // [max_beams] the same in fp32
-    PfBeamG* beams_occ_g = nullptr;    // [max_beams/4 + 1] the same in groups of four (k_measure_swz)
+    PfColG* beams_col = nullptr;       // [max_beams] the same grouped by local column (k_measure_col)
+    std::vector<PfColG> h_cols;
+    int n_cols = 0;
+    int col_ends[4] = {0, 0, 0, 0};    // ends of the 4-, 3-, 2-, 1-beam groups in beams_col
     int M_occ = 0;                     // padded to a multiple of PF_BEAM_GROUP
     int M_occ_real = 0;
     double lmax_occ = 0;               // max over occupied beams of max(|lx|+|ly|, |lz|)
@@ -91,7 +95,6 @@ struct pf_handle {
     std::vector<double> h_pose;
     std::vector<PfBeam> h_beams, h_beams_occ;
     std::vector<PfBeamF> h_beams_occ_f;
-    std::vector<PfBeamG> h_beams_occ_g;
     int tune_chunks = 0;               // SLAM_PF_CHUNKS (development knob)
     int force_exact_measure = 0;       // SLAM_PF_EXACT_MEASURE=1: fp64-only kernel
     int max_chunks = 1;
@@ -320,7 +323,7 @@ void pf_destroy(pf_handle* h) {
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
-    void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_occ_g,
+    void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_col,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
                     h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -424,12 +427,14 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
         // gather-layout copy for K1 when the 24-bit multiplies and 32-bit byte offsets of
         // swz_addr hold (any grid up to 1024^3 does); otherwise K1 reads the reference order
         const unsigned long long gx = c.grid_x, gy = c.grid_y, gz = c.grid_z;
-        const unsigned long long sbytes = gx * gy * 8ull * ((gz + 7) / 8);
-        if (c.map_mode == PF_MAP_SHARED && gx * gy * 8ull <= (1ull << 24) && sbytes < (1ull << 32) &&
+        const unsigned long long nx4 = (gx + 3) / 4, ny4 = (gy + 3) / 4, nz4 = (gz + 3) / 4;
+        const unsigned long long sa = ny4 * nz4 * 64, sb = nz4 * 64, sbytes = nx4 * sa;
+        const bool fits = sa < (1ull << 24) && nx4 < (1ull << 24) && ny4 < (1ull << 24);
+        if (c.map_mode == PF_MAP_SHARED && fits && sbytes < (1ull << 32) &&
             h->elements < (1ll << 31) && !getenv("SLAM_PF_NO_GATHER_LAYOUT")) {
             CREATE_TRY(dalloc(&h->shadow, (size_t)round_up(sbytes, 256)));
-            h->swz = PfSwz{(uint32_t)gx, (uint32_t)gy, (uint32_t)gz, (uint32_t)(gy * 8),
-                           (uint32_t)(gx * gy * 8 - 8)};
+            CREATE_TRY(hipMemsetAsync(h->shadow, 0, (size_t)round_up(sbytes, 256), h->stream));
+            h->swz = PfSwz{(uint32_t)gx, (uint32_t)gy, (uint32_t)gz, (uint32_t)sa, (uint32_t)sb};
         }
     }
     if (h->local_elements)
@@ -437,11 +442,12 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->beams, (size_t)c.max_beams));
     CREATE_TRY(dalloc(&h->beams_occ, (size_t)c.max_beams + PF_BEAM_GROUP));
     CREATE_TRY(dalloc(&h->beams_occ_f, (size_t)c.max_beams + PF_BEAM_GROUP));
-    CREATE_TRY(dalloc(&h->beams_occ_g, (size_t)c.max_beams / PF_BEAM_GROUP + 1));
+    CREATE_TRY(dalloc(&h->beams_col, (size_t)c.max_beams + 1));
     if (const char* e = getenv("SLAM_PF_GRAPH")) h->use_graphs = atoi(e) != 0;
     if (const char* e = getenv("SLAM_PF_SIDE")) h->use_side = atoi(e) != 0;
     if (const char* e = getenv("SLAM_PF_TWO_GATHERS")) h->group_gathers = atoi(e) == 0;
     if (const char* e = getenv("SLAM_PF_CHUNKS")) h->tune_chunks = atoi(e);
+    if (h->tune_chunks > h->max_chunks) h->max_chunks = h->tune_chunks < 1024 ? h->tune_chunks : 1024;
     if (h->tune_chunks > h->max_chunks) h->max_chunks = h->tune_chunks < 1024 ? h->tune_chunks : 1024;
     if (const char* e = getenv("SLAM_PF_EXACT_MEASURE")) h->force_exact_measure = atoi(e);
     CREATE_TRY(dalloc(&h->partial, (size_t)h->max_chunks * P));
@@ -651,16 +657,41 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         h->h_beams_occ_f.push_back(PfBeamF{-3.0e7f, 0.f, 0.f, 0});
     }
     const size_t no = h->h_beams_occ.size();
-    h->h_beams_occ_g.assign(no / PF_BEAM_GROUP, PfBeamG{});
-    for (size_t j = 0; j < no; ++j) {
-        PfBeamG& g = h->h_beams_occ_g[j / PF_BEAM_GROUP];
-        const PfBeam& b = h->h_beams_occ[j];
-        g.lx[j % PF_BEAM_GROUP] = (float)b.lx; g.ly[j % PF_BEAM_GROUP] = (float)b.ly;
-        g.lz[j % PF_BEAM_GROUP] = (int32_t)b.lz;
+    // column groups: runs of the list that share (lx, ly), at most four beams each, lz ascending
+    // inside a group; groups with more beams first (k_measure_col's phases), and dealing a phase
+    // round-robin gives every chunk the same share of it
+    h->h_cols.clear();
+    for (int j = 0; j < n_real_occ;) {
+        const PfBeam& b0 = h->h_beams_occ[(size_t)j];
+        PfColG g{};
+        g.lx = (float)b0.lx; g.ly = (float)b0.ly; g.n = 0;
+        while (j < n_real_occ && g.n < 4 && h->h_beams_occ[(size_t)j].lx == b0.lx &&
+               h->h_beams_occ[(size_t)j].ly == b0.ly) {
+            g.lz[g.n++] = (int32_t)h->h_beams_occ[(size_t)j].lz;
+            ++j;
+        }
+        std::sort(g.lz, g.lz + g.n);
+        for (int k = g.n; k < 4; ++k) g.lz[k] = g.lz[g.n - 1];
+        h->h_cols.push_back(g);
     }
-    if (no) {
-        HIP_TRY(h, hipMemcpyAsync(h->beams_occ_g, h->h_beams_occ_g.data(), sizeof(PfBeamG) * (no / PF_BEAM_GROUP),
+    // ... and inside a phase by range: how far the lanes of a wave spread over cache lines grows
+    // with the beam's range, so neighbours in this order cost about the same and go to different chunks
+    std::stable_sort(h->h_cols.begin(), h->h_cols.end(), [](const PfColG& a, const PfColG& b) {
+        if (a.n != b.n) return a.n > b.n;
+        return a.lx * a.lx + a.ly * a.ly > b.lx * b.lx + b.ly * b.ly;
+    });
+    h->n_cols = (int)h->h_cols.size();
+    {
+        int e = 0;
+        for (int n = 4; n >= 1; --n) {
+            while (e < h->n_cols && h->h_cols[(size_t)e].n == n) ++e;
+            h->col_ends[4 - n] = e;
+        }
+    }
+    if (h->n_cols)
+        HIP_TRY(h, hipMemcpyAsync(h->beams_col, h->h_cols.data(), sizeof(PfColG) * h->h_cols.size(),
                                   hipMemcpyHostToDevice, h->stream));
+    if (no) {
         HIP_TRY(h, hipMemcpyAsync(h->beams_occ, h->h_beams_occ.data(), sizeof(PfBeam) * no,
                                   hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->beams_occ_f, h->h_beams_occ_f.data(), sizeof(PfBeamF) * no,
@@ -727,10 +758,16 @@ int pf_measure(pf_handle* h, int add_points) {
     }
     {
         Timed t(h, PF_K_MEASURE);
-        if (swz)
-            HIP_TRY(h, pfk_measure_swz(h->stream, h->sorted, h->P, h->shadow, h->swz, h->beams_occ_g,
-                                       h->beams_occ, Mk, chunks, bpc, grid_params(h), h->lmax_occ,
-                                       h->order, h->partial));
+        if (swz) {
+            // >= 12 groups (about 32 beams) per chunk, like min_bpc above
+            int cch = h->tune_chunks > 0 ? h->tune_chunks : h->max_chunks;
+            if (cch > h->max_chunks) cch = h->max_chunks;
+            if (cch > (h->n_cols + 11) / 12) cch = (h->n_cols + 11) / 12;
+            if (cch < 1) cch = 1;
+            chunks = cch;
+            HIP_TRY(h, pfk_measure_col(h->stream, h->sorted, h->P, h->shadow, h->swz, h->beams_col, h->col_ends,
+                                       chunks, grid_params(h), h->lmax_occ, h->order, h->partial));
+        }
         else if (fuse)
             HIP_TRY(h, pfk_measure(h->stream, h->pose, h->P, h->maps, h->slab, h->beams, h->M, 1, bpc,
                                    grid_params(h), true, h->partial));
@@ -941,7 +978,7 @@ int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const dou
         grid = h->maps; up.elements = h->elements; up.gy = h->cfg.grid_y; up.gz = h->cfg.grid_z;
         up.is_signed = 0;
         if (h->shadow && !h->shadow_dirty) {        // keep K1's gather-layout copy in step
-            up.shadow = h->shadow; up.swz_gy8 = h->swz.gy8; up.swz_kz = h->swz.kz;
+            up.shadow = h->shadow; up.swz_a = h->swz.a; up.swz_b = h->swz.b;
         }
         NEED(h, p->hit_clamp >= 0 && p->hit_clamp <= 255 && p->miss_clamp >= 0 && p->miss_clamp <= 255, "clamps outside uint8");
     } else if (target == PF_GRID_LOCAL) {

@@ -18,17 +18,19 @@ struct PfBeamF {
     float lx, ly, lz;
     int32_t v;
 };
-// A group of PF_BEAM_GROUP occupied beams for k_measure_swz (64 B, scalar loads): lz as integers.
-struct __attribute__((aligned(64))) PfBeamG {
-    float lx[4], ly[4];
-    int32_t lz[4];
-    int32_t pad[4];
-};
-
-// Gather layout of the shared grid: byte address of cell (X, Y, Z) =
-// ((Z/8 * gx + X) * gy + Y) * 8 + Z%8; bytes = gx*gy*8*ceil(gz/8). gy8 = gy*8, kz = gx*gy*8 - 8.
+// Gather layout of the shared grid ("bricks"): 4 x 4 x 4 cells per 64-B line, byte address of cell
+// (X, Y, Z) = ((X/4 * ny4 + Y/4) * nz4 + Z/4) * 64 + (X%4)*16 + (Y%4)*4 + Z%4 with ny4 = ceil(gy/4),
+// nz4 = ceil(gz/4); bytes = ceil(gx/4)*ny4*nz4*64. a = ny4*nz4*64, b = nz4*64.
 struct PfSwz {
-    uint32_t gx, gy, gz, gy8, kz;
+    uint32_t gx, gy, gz, a, b;
+};
+// Up to four occupied beams of one local column (same lx, ly) for k_measure_col (32 B, one scalar
+// load): X, Y, the rounding test, the axis checks and the column's part of the address are per
+// column, only Z and the gather per beam. lz ascending; lz[k >= n] unused.
+struct __attribute__((aligned(32))) PfColG {
+    float lx, ly;
+    int32_t n, pad;
+    int32_t lz[4];
 };
 
 // Pose block: double [PF_POSE_ROWS][n] = x, y, z, yaw, cos, sin, x/res, y/res, z/res.
@@ -83,9 +85,10 @@ __device__ inline int order_key(const double* __restrict__ pose, int n, int i, P
 hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, int32_t* hist,
                      int32_t* next_hist, int32_t* order, double* sorted, PfOrderParams op,
                      bool hist_counted);
-// K1 on the gather layout (shared grid only). Same beam lists and chunking as pfk_measure_fast.
-hipError_t pfk_measure_swz(hipStream_t st, const double* sorted, int P, const uint8_t* shadow,
-                           PfSwz sw, const PfBeamG* bg, const PfBeam* bd, int M, int n_chunks, int bpc,
+// K1 on the gather layout (shared grid only), the beams grouped by column (PfColG) and the groups
+// sorted by their number of beams: group_ends = ends of the 4-, 3-, 2- and 1-beam groups in cg[].
+hipError_t pfk_measure_col(hipStream_t st, const double* sorted, int P, const uint8_t* shadow,
+                           PfSwz sw, const PfColG* cg, const int group_ends[4], int n_chunks,
                            PfGridParams gp, double lmax, const int32_t* order, int2* partial);
 hipError_t pfk_swz_build(hipStream_t st, const uint8_t* lin, uint8_t* shadow, PfSwz sw);
 // bmin: int32 [ceil(P/256)], the smallest sum_match of each 256-particle block
@@ -143,7 +146,7 @@ struct PfUpdateParams {
     int32_t hit_inc, hit_clamp, miss_inc, miss_clamp;
     int32_t is_signed;
     void* shadow;         // gather-layout copy of the shared grid to keep in step, or null
-    uint32_t swz_gy8, swz_kz;
+    uint32_t swz_a, swz_b;
 };
 hipError_t pfk_update_hits(hipStream_t st, void* grid, const double* points, int M, double* wpts,
                            PfUpdateParams up);

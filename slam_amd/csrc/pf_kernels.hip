@@ -306,12 +306,12 @@ __global__ __launch_bounds__(256) void k_measure_fast(
 }
 
 // ------------------------------------------------------------------------------------------
-// K1 on the shared grid's GATHER LAYOUT ("z-octet": [Z/8][X][Y][Z%8], a second copy of the
-// grid kept by pf_api.hip next to the reference-order one). The 64 lanes of a wave are near-
-// identical hypotheses, so for one beam they land within a few cells of each other in X, Y and
-// Z; in the reference's z-fastest order every distinct (X, Y) is a different cache line (6.8
-// lines per wave-wide gather measured on the bench scene), in this layout a 64-B line holds an
-// 8 (Y) x 8 (Z) tile and the same gathers touch 3.2 lines. The texture path's cost is per line.
+// K1 on the shared grid's GATHER LAYOUT (4 x 4 x 4 bricks, a second copy of the grid kept by
+// pf_api.hip next to the reference-order one). The 64 lanes of a wave are near-identical
+// hypotheses, so for one beam they land within a few cells of each other in X, Y and Z; in the
+// reference's z-fastest order every distinct (X, Y) is a different cache line (6.8 lines per
+// wave-wide gather measured on the bench scene), with one brick per 64-B line the same gathers
+// touch 2.3 lines, nine in ten at most four. The texture path's cost is per line beyond four.
 //
 // Per evaluation: xh = x + 0.5 and yh = y + 0.5 in fp32 (two FMAs each), X = floor(xh) (one
 // v_cvt_flr), g = fract(xh). The fp32 value is within E = 2^-22 (Lmax + max|T| + 1) of the
@@ -326,10 +326,16 @@ __device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c) 
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ unsigned swz_addr(unsigned X, unsigned Y, unsigned Z, unsigned gy8,
-                                             unsigned kz) {
-    // ((Z>>3)*gx*gy + X*gy + Y)*8 + (Z&7) = (Z>>3)*(gx*gy*8 - 8) + X*gy*8 + (Y*8 + Z)
-    return mad_u24(Z >> 3, kz, mad_u24(X, gy8, (Y << 3) + Z));
+// ((X>>2)*a + (Y>>2)*b + (Z>>2)*64) | (X&3)<<4 | (Y&3)<<2 | (Z&3); a, b multiples of 64
+__device__ __forceinline__ unsigned swz_col_base(unsigned X, unsigned Y, unsigned a, unsigned b) {
+    return mad_u24(X >> 2, a, mad_u24(Y >> 2, b, ((X & 3u) << 4) | ((Y & 3u) << 2)));
+}
+__device__ __forceinline__ unsigned swz_col_addr(unsigned base, unsigned Z, unsigned b) {
+    (void)b;
+    return (((Z & ~3u) << 4) + base) | (Z & 3u);
+}
+__device__ __forceinline__ unsigned swz_addr(unsigned X, unsigned Y, unsigned Z, unsigned a, unsigned b) {
+    return swz_col_addr(swz_col_base(X, Y, a, b), Z, b);
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -339,102 +345,151 @@ __device__ __forceinline__ int cvt_floor_i32(float x) {       // (int)floorf(x) 
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_measure_swz(
+// The beams are grouped by local column: the beams of a scan are the non-zero voxels of the local
+// map (S3P:868-877), several per (lx, ly) column; x and y of the transform, their rounding test,
+// the axis checks and the column's part of the address depend on the column only, so they are
+// done once per group of up to four beams and only Z, its part of the address and the gather
+// are per beam. The host sorts the groups by their number of beams, so the kernel runs four
+// straight-line phases (N = 4, 3, 2, 1 beams per group) without per-beam conditions.
+struct ColLane {                      // per-lane constants of k_measure_col
+    double c, s, ms, tx, ty, tz;
+    v2f rotA, rotB, trh;
+    int zp;
+    float E, hi;
+};
+struct ColGrid { unsigned gx, gy, gz, a, b; };
+
+// One trip: T (1 or 2) groups of N beams each. lz is ascending within a group, so the axis check
+// needs only the first and the last Z.
+template <int N, int T>
+__device__ __forceinline__ void col_trip(const PfColG* __restrict__ cg, int g, const ColLane& L,
+                                         const ColGrid& G, const PfGridParams& gp,
+                                         const uint8_t* __restrict__ shadow, int& sum, int& cnt) {
+    PfColG col[T];
+#pragma unroll
+    for (int q = 0; q < T; ++q) col[q] = cg[g + q];              // wave-uniform: scalar loads
+    int X[T], Y[T], Z[T][N];
+    float fx[T], fy[T];
+    bool fine = true;
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+        const v2f lxx = {col[q].lx, col[q].lx}, lyy = {col[q].ly, col[q].ly};
+        const v2f h = __builtin_elementwise_fma(L.rotA, lxx, __builtin_elementwise_fma(L.rotB, lyy, L.trh));
+        X[q] = cvt_floor_i32(h.x); Y[q] = cvt_floor_i32(h.y);
+        fx[q] = __builtin_amdgcn_fractf(h.x); fy[q] = __builtin_amdgcn_fractf(h.y);
+#pragma unroll
+        for (int k = 0; k < N; ++k) Z[q][k] = col[q].lz[k] + L.zp;
+        const unsigned zm = N > 1 ? max((unsigned)Z[q][0], (unsigned)Z[q][N - 1]) : (unsigned)Z[q][0];
+        fine = fine & (__builtin_fminf(fx[q], fy[q]) >= L.E) & (__builtin_fmaxf(fx[q], fy[q]) <= L.hi) &
+               ((unsigned)X[q] < G.gx) & ((unsigned)Y[q] < G.gy) & (zm < G.gz);
+    }
+    if (__builtin_expect(__all(fine), 1)) {
+        unsigned v[T][N];
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            const unsigned base = swz_col_base((unsigned)X[q], (unsigned)Y[q], G.a, G.b);
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[q][k] = shadow[swz_col_addr(base, (unsigned)Z[q][k], G.b)];
+        }
+        unsigned acc = 0;
+#pragma unroll
+        for (int q = 0; q < T; ++q)
+#pragma unroll
+            for (int k = 0; k < N; ++k) acc += v[q][k];          // S3P:887-888
+        sum += (int)acc;
+        cnt += T * N;
+        return;
+    }
+    // some lane is near a rounding boundary or off an axis: beam by beam
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+        const double dlx = (double)col[q].lx, dly = (double)col[q].ly;   // exact: integers below 2^24
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            unsigned xc = (unsigned)X[q], yc = (unsigned)Y[q], zc = (unsigned)Z[q][k];
+            bool ok = (xc < G.gx) & (yc < G.gy) & (zc < G.gz);
+            const bool good = (__builtin_fminf(fx[q], fy[q]) >= L.E) & (__builtin_fmaxf(fx[q], fy[q]) <= L.hi) & ok;
+            if (__any(!good)) {
+                // reference sequence S3P:745-747, 880, 85, then the cell the flat index names
+                const double Xd = round((L.c * dlx + L.ms * dly) + L.tx);
+                const double Yd = round((L.s * dlx + L.c * dly) + L.ty);
+                const double Zd = round((double)col[q].lz[k] + L.tz);
+                const double fd = fma(Xd, gp.gyz, fma(Yd, gp.gzd, Zd));
+                ok = (fd >= 0.0) & (fd < gp.elements);                 // S3P:882
+                const unsigned f = ok ? (unsigned)fd : 0u;
+                xc = f / (G.gy * G.gz);
+                const unsigned r = f - xc * (G.gy * G.gz);
+                yc = r / G.gz;
+                zc = r - yc * G.gz;
+            }
+            const unsigned vv = shadow[ok ? swz_addr(xc, yc, zc, G.a, G.b) : 0u];
+            sum += ok ? (int)vv : 0;
+            cnt += ok ? 1 : 0;
+        }
+    }
+}
+// One phase: the groups [g0, g1) all have N beams.
+template <int N>
+__device__ __forceinline__ void col_phase(const PfColG* __restrict__ cg, int g0, int g1, const ColLane& L,
+                                          const ColGrid& G, const PfGridParams& gp,
+                                          const uint8_t* __restrict__ shadow, int& sum, int& cnt) {
+    // pair slot pp = groups 2pp and 2pp+1 of the whole list belongs to chunk pp % gridDim.y, across
+    // the phase boundaries, so every chunk gets the same number of beams to within one pair
+    const int C = (int)gridDim.y, y = (int)blockIdx.y;
+    int pp = g0 / 2;
+    pp += (y - pp % C + C) % C;
+    for (; 2 * pp < g1; pp += C) {
+        const int ga = max(2 * pp, g0), gb = min(2 * pp + 2, g1);
+        if (gb - ga == 2) col_trip<N, 2>(cg, ga, L, G, gp, shadow, sum, cnt);
+        else col_trip<N, 1>(cg, ga, L, G, gp, shadow, sum, cnt);
+    }
+}
+
+// ends = {end of the 4-beam groups, of the 3-, of the 2-, of the 1-beam groups} in cg[]
+__global__ __launch_bounds__(256) void k_measure_col(
         const double* __restrict__ sorted, int P, const uint8_t* __restrict__ shadow, PfSwz sw,
-        const PfBeamG* __restrict__ bg, const PfBeam* __restrict__ bd, int M, int bpc,
-        PfGridParams gp, double lmax, const int32_t* __restrict__ order,
-        int2* __restrict__ partial, unsigned long long* __restrict__ trace) {
+        const PfColG* __restrict__ cg, int4 ends, PfGridParams gp,
+        double lmax, const int32_t* __restrict__ order, int2* __restrict__ partial,
+        unsigned long long* __restrict__ trace) {
+    // (raised before the prologue: a wave that still loads its pose while its neighbours already
+    // run the first phase at priority 3 is otherwise starved for half the launch)
+    __builtin_amdgcn_s_setprio(3);
     const int lane_id = blockIdx.x * 256 + threadIdx.x;
     const unsigned long long t_start = trace ? wall_clock64() : 0;
     if (lane_id >= P) return;
     // lane constants: coalesced loads of the rows k_order_scatter wrote in lane order
-    const double c = sorted[lane_id], s = sorted[(size_t)P + lane_id];
-    const double tx = sorted[2 * (size_t)P + lane_id], ty = sorted[3 * (size_t)P + lane_id];
-    const double tz = sorted[4 * (size_t)P + lane_id];
+    ColLane L;
+    L.c = sorted[lane_id]; L.s = sorted[(size_t)P + lane_id];
+    L.tx = sorted[2 * (size_t)P + lane_id]; L.ty = sorted[3 * (size_t)P + lane_id];
+    L.tz = sorted[4 * (size_t)P + lane_id];
     const int p = order[lane_id];
-    const double ms = -s;
-    const float cf = (float)c, sf = (float)s, msf = -sf;
-    const float txh = (float)(tx + 0.5), tyh = (float)(ty + 0.5);
-    const v2f rotA = {cf, sf}, rotB = {msf, cf}, trh = {txh, tyh};
-    const int zp = (int)round(tz);                               // exact: |tz| < 2^24
-    const double tmax = fmax(fmax(fabs(tx), fabs(ty)), fabs(tz));
-    float E = (float)(2.5e-7 * (lmax + tmax + 1.0) + 1.0e-7);
-    if (z_is_ambiguous(tz)) E = 2.0f;                            // every beam of this wave: fp64
-    const float hi = (float)(1.0 - (double)E);
-    const unsigned gxu = sw.gx, gyu = sw.gy, gzu = sw.gz, gy8 = sw.gy8, kz = sw.kz;
-    // Beam groups are dealt to the chunks (blockIdx.y) round-robin: the list is in the reference's
-    // x-major order (S3P:868), so contiguous chunks would differ in range and bearing, hence in
-    // cache lines per gather, and the launch would last as long as its most divergent chunk.
-    (void)bpc;
+    L.ms = -L.s;
+    const float cf = (float)L.c, sf = (float)L.s;
+    L.rotA = v2f{cf, sf}; L.rotB = v2f{-sf, cf};
+    L.trh = v2f{(float)(L.tx + 0.5), (float)(L.ty + 0.5)};
+    L.zp = (int)round(L.tz);                                     // exact: |tz| < 2^24
+    const double tmax = fmax(fmax(fabs(L.tx), fabs(L.ty)), fabs(L.tz));
+    L.E = (float)(2.5e-7 * (lmax + tmax + 1.0) + 1.0e-7);
+    if (z_is_ambiguous(L.tz)) L.E = 2.0f;                        // every beam of this wave: fp64
+    L.hi = (float)(1.0 - (double)L.E);
+    const ColGrid G{sw.gx, sw.gy, sw.gz, sw.a, sw.b};
     int sum = 0, cnt = 0;
-    const unsigned long long t_loop = trace ? wall_clock64() + (E > 3.0f ? 1 : 0) : 0;
+    const unsigned long long t_loop = trace ? wall_clock64() + (L.E > 3.0f ? 1 : 0) : 0;
     // The issue arbiter favours the oldest wave, which staggers the finish times of a launch
-    // that is one residency deep and leaves the CUs half empty at the end. Waves in the first
-    // half of their beams therefore run at a higher priority than waves in the second half.
+    // that is one residency deep and leaves the CUs half empty at the end. Priority therefore
+    // follows progress: 3 from the first instruction through the four-beam phase, then 2, 1, 0.
+    // (Measured against it: 3 for the prologue only and 2/1/0/0 for the phases, 31.4 vs 30.6 us;
+    // steps at thirds of the wave's beams, 32.3-33.4 us.)
     // (Tried instead, and slower: a per-slot work queue that hands beam batches to whichever
     // wave is free, 44 us against 39 us, the same-address atomics cost more than the tail;
     // an XCD-aware chunk map so each L2 sees an eighth of the beams, no measurable change.)
-    const int j_half = M / 2;
+    col_phase<4>(cg, 0, ends.x, L, G, gp, shadow, sum, cnt);
     __builtin_amdgcn_s_setprio(2);
-    for (int j = blockIdx.y * PF_BEAM_GROUP; j < M; j += gridDim.y * PF_BEAM_GROUP) {
-        if (j >= j_half) __builtin_amdgcn_s_setprio(0);
-        const PfBeamG g = bg[j / PF_BEAM_GROUP];     // wave-uniform: scalar loads
-        int X[PF_BEAM_GROUP], Y[PF_BEAM_GROUP], Z[PF_BEAM_GROUP];
-        float gmin = 0.5f, gmax = 0.5f;
-        bool okall = true;
-#pragma unroll
-        for (int k = 0; k < PF_BEAM_GROUP; ++k) {
-            // (xh, yh) as one packed pair: two v_pk_fma_f32, the beam's lx / ly broadcast from SGPRs
-            const v2f lxx = {g.lx[k], g.lx[k]}, lyy = {g.ly[k], g.ly[k]};
-            const v2f h = __builtin_elementwise_fma(rotA, lxx, __builtin_elementwise_fma(rotB, lyy, trh));
-            X[k] = cvt_floor_i32(h.x); Y[k] = cvt_floor_i32(h.y); Z[k] = g.lz[k] + zp;
-            const float fx = __builtin_amdgcn_fractf(h.x), fy = __builtin_amdgcn_fractf(h.y);
-            gmin = __builtin_fminf(gmin, __builtin_fminf(fx, fy));
-            gmax = __builtin_fmaxf(gmax, __builtin_fmaxf(fx, fy));
-        }
-        // axis ranges once per group: as unsigned, a negative coordinate is a huge one
-        const unsigned xm = max(max((unsigned)X[0], (unsigned)X[1]), max((unsigned)X[2], (unsigned)X[3]));
-        const unsigned ym = max(max((unsigned)Y[0], (unsigned)Y[1]), max((unsigned)Y[2], (unsigned)Y[3]));
-        const unsigned zm = max(max((unsigned)Z[0], (unsigned)Z[1]), max((unsigned)Z[2], (unsigned)Z[3]));
-        okall = (xm < gxu) & (ym < gyu) & (zm < gzu);
-        const bool fine = (gmin >= E) & (gmax <= hi) & okall;
-        if (__builtin_expect(__all(fine), 1)) {
-            unsigned v[PF_BEAM_GROUP];
-#pragma unroll
-            for (int k = 0; k < PF_BEAM_GROUP; ++k)
-                v[k] = shadow[swz_addr((unsigned)X[k], (unsigned)Y[k], (unsigned)Z[k], gy8, kz)];
-            sum += (int)((v[0] + v[1]) + (v[2] + v[3]));         // S3P:887-888
-            cnt += PF_BEAM_GROUP;
-            continue;
-        }
-        // some lane is near a rounding boundary or off an axis: beam by beam
-        for (int k = 0; k < PF_BEAM_GROUP; ++k) {
-            const float xh = fmaf(cf, g.lx[k], fmaf(msf, g.ly[k], txh));
-            const float yh = fmaf(sf, g.lx[k], fmaf(cf, g.ly[k], tyh));
-            const float fx = __builtin_amdgcn_fractf(xh), fy = __builtin_amdgcn_fractf(yh);
-            unsigned xc = (unsigned)cvt_floor_i32(xh), yc = (unsigned)cvt_floor_i32(yh);
-            unsigned zc = (unsigned)(g.lz[k] + zp);
-            bool ok = (xc < gxu) & (yc < gyu) & (zc < gzu);
-            const bool good = (__builtin_fminf(fx, fy) >= E) & (__builtin_fmaxf(fx, fy) <= hi) & ok;
-            if (__any(!good)) {
-                // reference sequence S3P:745-747, 880, 85, then the cell the flat index names
-                const PfBeam d = bd[j + k];
-                const double Xd = round((c * d.lx + ms * d.ly) + tx);
-                const double Yd = round((s * d.lx + c * d.ly) + ty);
-                const double Zd = round(d.lz + tz);
-                const double fd = fma(Xd, gp.gyz, fma(Yd, gp.gzd, Zd));
-                ok = (fd >= 0.0) & (fd < gp.elements);                 // S3P:882
-                const unsigned f = ok ? (unsigned)fd : 0u;
-                xc = f / (gyu * gzu);
-                const unsigned r = f - xc * (gyu * gzu);
-                yc = r / gzu;
-                zc = r - yc * gzu;
-            }
-            const unsigned v = shadow[ok ? swz_addr(xc, yc, zc, gy8, kz) : 0u];
-            sum += ok ? (int)v : 0;
-            cnt += ok ? 1 : 0;
-        }
-    }
+    col_phase<3>(cg, ends.x, ends.y, L, G, gp, shadow, sum, cnt);
+    __builtin_amdgcn_s_setprio(1);
+    col_phase<2>(cg, ends.y, ends.z, L, G, gp, shadow, sum, cnt);
+    __builtin_amdgcn_s_setprio(0);
+    col_phase<1>(cg, ends.z, ends.w, L, G, gp, shadow, sum, cnt);
     partial[(size_t)blockIdx.y * P + p] = make_int2(sum, cnt);
     if (trace && (threadIdx.x & 63) == 0) {          // development aid: per-wave timeline
         const size_t w = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -443,20 +498,22 @@ __global__ __launch_bounds__(256) void k_measure_swz(
     }
 }
 
-// reference order -> gather layout, one thread per octet (8 cells of one (X, Y) column)
+// reference order -> gather layout, one thread per dword (4 z-consecutive cells of one (X, Y))
 __global__ __launch_bounds__(256) void k_swz_build(const uint8_t* __restrict__ lin,
-                                                   uint2* __restrict__ shadow, PfSwz sw) {
+                                                   uint8_t* __restrict__ shadow, PfSwz sw) {
     const unsigned o = blockIdx.x * 256u + threadIdx.x;
-    const unsigned nzq = (sw.gz + 7u) / 8u, gxy = sw.gx * sw.gy;
-    if (o >= nzq * gxy) return;
-    const unsigned zq = o / gxy, rem = o - zq * gxy;              // rem = X*gy + Y
-    const uint8_t* src = lin + (size_t)rem * sw.gz + zq * 8u;
-    unsigned w[2] = {0u, 0u};
+    const unsigned nz4 = (sw.gz + 3u) / 4u, gxy = sw.gx * sw.gy;
+    if (o >= nz4 * gxy) return;
+    const unsigned rem = o / nz4, zq = o - rem * nz4;             // rem = X*gy + Y
+    const unsigned X = rem / sw.gy, Y = rem - X * sw.gy;
+    const uint8_t* src = lin + (size_t)rem * sw.gz + zq * 4u;
+    unsigned w = 0u;
 #pragma unroll
-    for (unsigned k = 0; k < 8; ++k)
-        if (zq * 8u + k < sw.gz) w[k >> 2] |= (unsigned)src[k] << (8u * (k & 3u));
-    shadow[o] = make_uint2(w[0], w[1]);
+    for (unsigned k = 0; k < 4; ++k)
+        if (zq * 4u + k < sw.gz) w |= (unsigned)src[k] << (8u * k);
+    *(unsigned*)(shadow + swz_addr(X, Y, zq * 4u, sw.a, sw.b)) = w;
 }
+static unsigned swz_build_threads(PfSwz sw) { return (sw.gz + 3u) / 4u * sw.gx * sw.gy; }
 
 __global__ __launch_bounds__(256) void k_reduce_scores(const int2* __restrict__ partial,
                                                        int n_chunks, int P,
@@ -539,8 +596,8 @@ hipError_t pfk_measure_fast(hipStream_t st, const double* pose, int P, const uin
     return hipGetLastError();
 }
 
-hipError_t pfk_measure_swz(hipStream_t st, const double* sorted, int P, const uint8_t* shadow,
-                           PfSwz sw, const PfBeamG* bg, const PfBeam* bd, int M, int n_chunks, int bpc,
+hipError_t pfk_measure_col(hipStream_t st, const double* sorted, int P, const uint8_t* shadow,
+                           PfSwz sw, const PfColG* cg, const int group_ends[4], int n_chunks,
                            PfGridParams gp, double lmax, const int32_t* order, int2* partial) {
     // SLAM_PF_K1_TRACE=<file>: development aid, dumps {start, loop start, end, HW_ID} per wave
     static unsigned long long* trace = nullptr;
@@ -551,8 +608,9 @@ hipError_t pfk_measure_swz(hipStream_t st, const double* sorted, int P, const ui
         if (hipMalloc((void**)&trace, 8 * trace_n) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(trace, 0, 8 * trace_n, st);
     }
-    hipLaunchKernelGGL(k_measure_swz, dim3((P + 255) / 256, n_chunks), dim3(256), 0, st, sorted, P,
-                       shadow, sw, bg, bd, M, bpc, gp, lmax, order, partial, trace_path ? trace : nullptr);
+    hipLaunchKernelGGL(k_measure_col, dim3((P + 255) / 256, n_chunks), dim3(256), 0, st, sorted, P, shadow,
+                       sw, cg, make_int4(group_ends[0], group_ends[1], group_ends[2], group_ends[3]), gp, lmax,
+                       order, partial, trace_path ? trace : nullptr);
     if (trace_path) {
         (void)hipStreamSynchronize(st);
         std::vector<unsigned long long> hbuf(trace_n);
@@ -563,8 +621,8 @@ hipError_t pfk_measure_swz(hipStream_t st, const double* sorted, int P, const ui
     return hipGetLastError();
 }
 hipError_t pfk_swz_build(hipStream_t st, const uint8_t* lin, uint8_t* shadow, PfSwz sw) {
-    const unsigned n = (sw.gz + 7u) / 8u * sw.gx * sw.gy;
-    hipLaunchKernelGGL(k_swz_build, dim3((n + 255u) / 256u), dim3(256), 0, st, lin, (uint2*)shadow, sw);
+    const unsigned n = swz_build_threads(sw);
+    hipLaunchKernelGGL(k_swz_build, dim3((n + 255u) / 256u), dim3(256), 0, st, lin, shadow, sw);
     return hipGetLastError();
 }
 
@@ -755,7 +813,7 @@ __device__ inline void shadow_touch(const PfUpdateParams& up, long long f, int i
     const unsigned fu = (unsigned)f, gyz = (unsigned)(up.gy * up.gz);
     const unsigned xc = fu / gyz, r = fu - xc * gyz, yc = r / (unsigned)up.gz;
     const unsigned zc = r - yc * (unsigned)up.gz;
-    cell_touch(up.shadow, (long long)swz_addr(xc, yc, zc, up.swz_gy8, up.swz_kz), inc, clampv, hit, false);
+    cell_touch(up.shadow, (long long)swz_addr(xc, yc, zc, up.swz_a, up.swz_b), inc, clampv, hit, false);
 }
 
 __global__ __launch_bounds__(256) void k_update_hits(void* grid, const double* __restrict__ points,

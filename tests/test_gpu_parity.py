@@ -257,7 +257,7 @@ def test_systematic_thresholds_same_kernel():
 
 @pytest.mark.parametrize("dims", [(32, 24, 16), (31, 23, 19)])
 def test_edge_cases_bounds_aliasing_and_empty(dims):
-    """dims not multiples of 8 exercise the padding of K1's gather layout (8-cell z octets)."""
+    """dims not multiples of 4 exercise the padding of K1's gather layout (4 x 4 x 4 bricks)."""
     P = 130
     rng = np.random.default_rng(5)
     grid = rng.integers(0, 101, dims).astype(np.uint8)

@@ -24,7 +24,8 @@ for w, idx in enumerate(order):
     Z = np.rint(lz + z[idx, None])
     Xi, Yi, Zi = X.astype(np.int64), Y.astype(np.int64), Z.astype(np.int64)
     if len(sys.argv) > 1 and sys.argv[1] == "zoct":
-        f = (((Zi >> 3) * G + Xi) * G + Yi) * 8 + (Zi & 7)
+        n4 = (G + 3) // 4                                     # 4x4x4 bricks, as swz_addr in pf_kernels.hip
+        f = (((Xi >> 2) * n4 + (Yi >> 2)) * n4 + (Zi >> 2)) * 64 + (Xi & 3) * 16 + (Yi & 3) * 4 + (Zi & 3)
     elif len(sys.argv) > 1 and sys.argv[1] == "brick":
         f = ((((Xi >> 2) * (G // 4) + (Yi >> 2)) * (G // 4) + (Zi >> 2)) * 64 + (Xi & 3) * 16 + (Yi & 3) * 4 + (Zi & 3))
     else:

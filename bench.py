@@ -46,6 +46,9 @@ def parse():
                     help="HIP events around K3/K4/K5 too (kernel_us); costs host time in the step")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="sharded runs: all-gathers through torch.distributed instead of the library's own RCCL calls")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="read every step's results before the next step is enqueued (pf_resample) instead of "
+                         "one step later (pf_resample_async / pf_resample_result)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal: use the multi-GPU code path (RCCL all-gathers) even at N=1")
     return ap.parse_args()
@@ -192,7 +195,7 @@ def main():
     block_ptrs = [blocks[b].data_ptr() for b in range(NBLK)]
     step_no = [0]
 
-    def step(first=False):
+    def enqueue(first=False):
         be.measure(0)
         if not a.no_update:
             # the grid update only has to follow this step's measure and precede the next one
@@ -200,6 +203,9 @@ def main():
         h.predict_device(block_ptrs[step_no[0] % NBLK])
         step_no[0] += 1
         be.weights()
+
+    def step(first=False):
+        enqueue()
         return be.resample(u if first else None, want_slots=False)
 
     def fence():
@@ -216,8 +222,21 @@ def main():
     fence()
     t0 = time.perf_counter()
     amb_total = nohit_total = 0
-    for _ in range(a.steps):
-        _, _, nohit, amb = step()
+    if a.no_pipeline:
+        for _ in range(a.steps):
+            _, _, nohit, amb = step()
+            amb_total += amb; nohit_total += nohit
+    else:
+        # every step's work and every step's results, the results read one step late: step i+1 is
+        # enqueued before the host waits for step i (its inputs here do not depend on them, and the
+        # reference feeds the filter's correction back asynchronously too, S3P:956-959 / 712-716)
+        for i in range(a.steps):
+            enqueue()
+            be.resample_async(None, want_slots=False) if sharded else h.resample_async(None, None, False)
+            if i:
+                _, _, nohit, amb = be.resample_result()
+                amb_total += amb; nohit_total += nohit
+        _, _, nohit, amb = be.resample_result()
         amb_total += amb; nohit_total += nohit
     fence()
     el = time.perf_counter() - t0
@@ -249,6 +268,8 @@ def main():
                        "particles_per_gpu": P, "particles_total": Pg, "beams": M,
                        "grid": list(dims), "order": "fast" if Pg > 2048 else "exact",
                        "collectives": ("rccl in-library" if getattr(be, "native", False) else "torch.distributed nccl") if sharded else "none",
+                       "results_read": "every step, before the next is enqueued" if a.no_pipeline
+                                       else "every step, one step late (pf_resample_async)",
                        "ambiguous_draws": int(amb_total), "nohit_draws": int(nohit_total)},
             "roofline": {"bound": "hbm", "kernel": "k_measure_col", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,

@@ -149,6 +149,15 @@ int pf_weights(pf_handle* h, const void* scores_global_dev);
 int pf_resample(pf_handle* h, const double* u_global, const void* poses_global_dev,
                 int32_t* slot_anc_out, int32_t* best_out, int64_t* nohit_out,
                 int64_t* ambiguous_out);
+/* The same in two halves, for callers that do not need a step's results before they enqueue the
+ * next one (the reference applies the filter's correction asynchronously itself: S3P:956-959
+ * writes globals the camera callback consumes later, S3P:712-716). pf_resample_async enqueues
+ * everything pf_resample does and returns; slot_anc_out (may be NULL) is filled by the time the
+ * matching pf_resample_result returns. pf_resample_result blocks until the OLDEST outstanding
+ * resample has finished and hands out its results. At most two may be outstanding (PF_ERR_STATE
+ * otherwise); pf_resample itself refuses while one is. */
+int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_dev, int32_t* slot_anc_out);
+int pf_resample_result(pf_handle* h, int32_t* best_out, int64_t* nohit_out, int64_t* ambiguous_out);
 /* device pointer to the local pose block, double [9][n_particles]:
  * x, y, z, yaw, cos, sin, x/res, y/res, z/res. */
 void* pf_poses_device(pf_handle* h);

@@ -22,6 +22,7 @@ SYMBOLS = (
     "pf_default_config pf_create pf_destroy pf_last_error pf_predict pf_predict_device pf_get_poses pf_set_weights "
     "pf_get_weights pf_fill_maps pf_write_map pf_broadcast_map pf_read_map pf_set_beams "
     "pf_measure pf_get_scores pf_scores_device pf_voxel_indices pf_weights pf_resample "
+    "pf_resample_async pf_resample_result "
     "pf_poses_device pf_set_scan pf_update_map pf_scan_vote pf_write_local_map pf_read_local_map "
     "pf_reset_local_map pf_stream pf_set_stream pf_synchronize pf_profile pf_kernel_time "
     "pfh_snapshot_beams pfh_predict pfh_draw_noise pfh_draw_uniform pfh_add_points_policy "
@@ -240,6 +241,24 @@ class Handle:
         best = C.c_int32(-1); nohit = C.c_int64(0); amb = C.c_int64(0)
         self._ck(lib().pf_resample(self._h, _p(u), C.c_void_p(poses_global_dev), _p(slots),
                                    C.byref(best), C.byref(nohit), C.byref(amb)), "pf_resample")
+        return slots, best.value, nohit.value, amb.value
+
+    def resample_async(self, u=None, poses_global_dev=None, want_slots=False):
+        """Enqueue only; the results (and the slots, when asked for) come with resample_result()."""
+        if u is not None:
+            u = _c(u, np.float64)
+            assert len(u) == self.Pg
+        slots = np.empty(self.Pg, np.int32) if want_slots else None
+        self._ck(lib().pf_resample_async(self._h, _p(u), C.c_void_p(poses_global_dev), _p(slots)),
+                 "pf_resample_async")
+        self._pending_slots = getattr(self, "_pending_slots", [])
+        self._pending_slots.append(slots)
+
+    def resample_result(self):
+        best = C.c_int32(-1); nohit = C.c_int64(0); amb = C.c_int64(0)
+        self._ck(lib().pf_resample_result(self._h, C.byref(best), C.byref(nohit), C.byref(amb)),
+                 "pf_resample_result")
+        slots = self._pending_slots.pop(0) if getattr(self, "_pending_slots", None) else None
         return slots, best.value, nohit.value, amb.value
 
     # --- map update ---

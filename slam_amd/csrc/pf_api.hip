@@ -75,8 +75,12 @@ struct pf_handle {
     int32_t* free_slot = nullptr;      // [Pg]
     int32_t* slot_anc = nullptr;       // [Pg]
     int32_t* best = nullptr;           // inside `counters`' allocation: one D2H copy returns all
-    unsigned long long* h_result = nullptr;    // pinned host memory K4's last kernel writes {counters[3], best} to
+    // pinned host memory K4's last kernel writes {counters[3], best} to: two slots, so that one
+    // resample may be in flight while the next step is enqueued (pf_resample_async / _result)
+    unsigned long long* h_result = nullptr;    // [2][4]
     unsigned long long* d_result = nullptr;    // the same memory as the device sees it
+    hipEvent_t rs_event[2] = {nullptr, nullptr};   // recorded behind each slot's resample
+    unsigned long long rs_issued = 0, rs_done = 0; // resamples enqueued / results handed out
     unsigned long long* counters = nullptr;   // [3]
     PfResampleScratch rs{};            // block-level scratch of K3/K4
     void* rs_mem = nullptr;
@@ -102,14 +106,6 @@ struct pf_handle {
     int n_points = 0, n_rays = 0;
     bool measured = false, weighted = false, have_u = false;
     bool exact = true;
-    // K3 and K4 are chains of small fixed-argument kernels: with SLAM_PF_GRAPH=1 each chain is
-    // captured once into a hipGraph and replayed (one launch instead of 5 and 8). Key = the
-    // pointer argument that can differ between calls. Off by default: measured on ROCm 7.2 the
-    // replay is SLOWER than the plain launches (K3 24.7 vs 18.0 us, K4 36.5 vs 28.7 us, step
-    // 167.6 vs 151.4 us; profiles/README.md).
-    struct GraphSlot { hipGraphExec_t exec = nullptr; const void* key = nullptr; bool bad = false; };
-    GraphSlot g_weights, g_resample;
-    bool use_graphs = false;
     // The shared-grid update (K5) depends on nothing K3/K4 produce and nothing but K1, K6 and the
     // map accessors read what it writes: with SLAM_PF_SIDE=1 it runs on a side stream, after the
     // map readers already enqueued, and the next map reader waits for it. Off by default: the
@@ -181,32 +177,6 @@ PfGridParams grid_params(const pf_handle* h) {
     gp.lo = h->cfg.map_lo;
     gp.hi = h->cfg.map_hi;
     return gp;
-}
-
-// Runs `launch` (which enqueues kernels on h->stream) through a cached graph.
-template <class F>
-hipError_t run_graph(pf_handle* h, pf_handle::GraphSlot& slot, const void* key, F&& launch) {
-    if (!h->use_graphs || slot.bad) return launch();
-    if (slot.exec && slot.key == key) return hipGraphLaunch(slot.exec, h->stream);
-    if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
-    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-        (void)hipGetLastError();
-        slot.bad = true;
-        return launch();
-    }
-    const hipError_t el = launch();
-    hipGraph_t g = nullptr;
-    const hipError_t ec = hipStreamEndCapture(h->stream, &g);
-    hipError_t ei = hipErrorUnknown;
-    if (el == hipSuccess && ec == hipSuccess && g) ei = hipGraphInstantiate(&slot.exec, g, nullptr, nullptr, 0);
-    if (g) (void)hipGraphDestroy(g);
-    if (ei != hipSuccess) {
-        (void)hipGetLastError();
-        slot.exec = nullptr; slot.bad = true;
-        return launch();
-    }
-    slot.key = key;
-    return hipGraphLaunch(slot.exec, h->stream);
 }
 
 // The poses the last pf_resample counted K1's order keys for are being replaced.
@@ -332,8 +302,7 @@ void pf_destroy(pf_handle* h) {
     if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
     if (h->scores_all) (void)hipFree(h->scores_all);
     if (h->poses_all) (void)hipFree(h->poses_all);
-    if (h->g_weights.exec) (void)hipGraphExecDestroy(h->g_weights.exec);
-    if (h->g_resample.exec) (void)hipGraphExecDestroy(h->g_resample.exec);
+    for (hipEvent_t e : h->rs_event) if (e) (void)hipEventDestroy(e);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -443,7 +412,6 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->beams_occ, (size_t)c.max_beams + PF_BEAM_GROUP));
     CREATE_TRY(dalloc(&h->beams_occ_f, (size_t)c.max_beams + PF_BEAM_GROUP));
     CREATE_TRY(dalloc(&h->beams_col, (size_t)c.max_beams + 1));
-    if (const char* e = getenv("SLAM_PF_GRAPH")) h->use_graphs = atoi(e) != 0;
     if (const char* e = getenv("SLAM_PF_SIDE")) h->use_side = atoi(e) != 0;
     if (const char* e = getenv("SLAM_PF_TWO_GATHERS")) h->group_gathers = atoi(e) == 0;
     if (const char* e = getenv("SLAM_PF_CHUNKS")) h->tune_chunks = atoi(e);
@@ -460,8 +428,10 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->slot_anc, Pg));
     CREATE_TRY(dalloc(&h->counters, 4));            // [0..2] counters, [3] holds `best`
     h->best = (int32_t*)(h->counters + 3);
-    CREATE_TRY(hipHostMalloc((void**)&h->h_result, 4 * sizeof(unsigned long long), hipHostMallocMapped));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_result, 8 * sizeof(unsigned long long), hipHostMallocMapped));
     CREATE_TRY(hipHostGetDevicePointer((void**)&h->d_result, h->h_result, 0));
+    CREATE_TRY(hipEventCreateWithFlags(&h->rs_event[0], hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->rs_event[1], hipEventDisableTiming));
     {
         // one allocation, carved: 6 double arrays of nb (+8 for prm), 2 int2 arrays, 1 int array, ndup
         const size_t nb = (Pg + 255) / 256;
@@ -837,18 +807,17 @@ int pf_weights(pf_handle* h, const void* scores_global_dev) {
     }
     {
         Timed t(h, PF_K_WEIGHTS);
-        HIP_TRY(h, run_graph(h, h->g_weights, sc, [&] {
-            return pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact, h->first,
-                               h->counters, h->rs, sc == h->scores && h->P == h->Pg ? h->bmin : nullptr);
-        }));
+        HIP_TRY(h, pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact, h->first,
+                               h->counters, h->rs, sc == h->scores && h->P == h->Pg ? h->bmin : nullptr));
     }
     h->weighted = true;
     return PF_OK;
 }
 
-int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int32_t* slot_anc_out,
-                int32_t* best_out, int64_t* nohit_out, int64_t* ambiguous_out) {
+int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_dev, int32_t* slot_anc_out) {
     if (!h) return PF_ERR_ARG;
+    if (h->rs_issued - h->rs_done >= 2)
+        return fail(h, PF_ERR_STATE, "pf_resample_async: two resamples already wait for pf_resample_result");
     if (!h->weighted) return fail(h, PF_ERR_STATE, "pf_resample before pf_weights");
     if (!u && !h->have_u) return fail(h, PF_ERR_ARG, "pf_resample: no thresholds resident");
     if (h->Pg != h->P && !poses_global_dev && !h->comm)
@@ -872,7 +841,7 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->have_u = true;
     }
-    unsigned long long cnt[3] = {0, 0, 0};
+    const int slot = (int)(h->rs_issued & 1ull);
     {
         Timed t(h, PF_K_RESAMPLE);
         // FAST order: the parallel sum/scan differs from the sequential one by at most a few
@@ -880,15 +849,12 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
         const double bound = h->exact ? 0.0 : 8.0 * (double)h->Pg * 1.1102230246251565e-16;
         // one GPU, shared-key ordering: the fill stage leaves K1's order keys of the new poses
         const PfOrderParams op = order_params(h);
-        const bool count_keys = h->P == h->Pg && !poses_global_dev && op.mode != 0 && op.bits == 4 &&
-                                !h->use_graphs;
-        HIP_TRY(h, run_graph(h, h->g_resample, poses_global_dev, [&] {
-            return pfk_resample(h->stream, h->cdf, h->u, h->Pg, h->P, h->offset, bound, h->w, h->logw,
+        const bool count_keys = h->P == h->Pg && !poses_global_dev && op.mode != 0 && op.bits == 4;
+        HIP_TRY(h, pfk_resample(h->stream, h->cdf, h->u, h->Pg, h->P, h->offset, bound, h->w, h->logw,
                                 h->pose, (const double*)poses_global_dev, h->slab ? h->maps : nullptr,
                                 h->slab, (unsigned long long)h->elements, h->draw, h->first, h->dup_anc,
-                                h->free_slot, h->slot_anc, h->best, h->counters, h->rs, h->d_result,
-                                count_keys ? h->order_hist[0] : nullptr, h->order_keys, op);
-        }));
+                                h->free_slot, h->slot_anc, h->best, h->counters, h->rs, h->d_result + 4 * slot,
+                                count_keys ? h->order_hist[0] : nullptr, h->order_keys, op));
         h->hist_counted = count_keys;
     }
     if (slot_anc_out)
@@ -934,15 +900,37 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
             if (r != ncclSuccess) return fail(h, PF_ERR_HIP, "pf_resample: map migration: %s", rccl().GetErrorString(r));
         }
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    cnt[0] = h->h_result[0]; cnt[1] = h->h_result[1]; cnt[2] = h->h_result[2];
-    if (best_out) *best_out = (int32_t)(h->h_result[3] & 0xffffffffull);
+    HIP_TRY(h, hipEventRecord(h->rs_event[slot], h->stream));
+    ++h->rs_issued;
     h->order_dirty = true;
-    if (nohit_out) *nohit_out = (int64_t)(cnt[1] ? cnt[2] : cnt[0]);
-    if (ambiguous_out) *ambiguous_out = (int64_t)cnt[1];
     h->weighted = false;
     h->measured = false;
     return PF_OK;
+}
+
+int pf_resample_result(pf_handle* h, int32_t* best_out, int64_t* nohit_out, int64_t* ambiguous_out) {
+    if (!h) return PF_ERR_ARG;
+    if (h->rs_done == h->rs_issued) return fail(h, PF_ERR_STATE, "pf_resample_result: no resample outstanding");
+    const int slot = (int)(h->rs_done & 1ull);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipEventSynchronize(h->rs_event[slot]));
+    const unsigned long long* r = h->h_result + 4 * slot;
+    const unsigned long long cnt[3] = {r[0], r[1], r[2]};
+    if (best_out) *best_out = (int32_t)(r[3] & 0xffffffffull);
+    if (nohit_out) *nohit_out = (int64_t)(cnt[1] ? cnt[2] : cnt[0]);
+    if (ambiguous_out) *ambiguous_out = (int64_t)cnt[1];
+    ++h->rs_done;
+    return PF_OK;
+}
+
+int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int32_t* slot_anc_out,
+                int32_t* best_out, int64_t* nohit_out, int64_t* ambiguous_out) {
+    if (!h) return PF_ERR_ARG;
+    if (h->rs_issued != h->rs_done)
+        return fail(h, PF_ERR_STATE, "pf_resample: a pf_resample_async still waits for pf_resample_result");
+    const int rc = pf_resample_async(h, u, poses_global_dev, slot_anc_out);
+    if (rc != PF_OK) return rc;
+    return pf_resample_result(h, best_out, nohit_out, ambiguous_out);
 }
 
 int pf_set_scan(pf_handle* h, const double* points, int64_t n_points, const int32_t* ray_idx,

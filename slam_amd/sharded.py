@@ -110,6 +110,17 @@ class ShardedBackend:
         self._after_collective(self._poses_all)
         return self.h.resample(u, self._poses_all.data_ptr(), want_slots)
 
+    def resample_async(self, u=None, want_slots=False):
+        if self.native:
+            return self.h.resample_async(u, None, want_slots)
+        self._before_collective()
+        self.dist.all_gather_into_tensor(self._poses_all, self._poses, group=self.group)     # C2
+        self._after_collective(self._poses_all)
+        return self.h.resample_async(u, self._poses_all.data_ptr(), want_slots)
+
+    def resample_result(self):
+        return self.h.resample_result()
+
     def best_pose(self, best):
         """(x, y, z, yaw) of global slot `best` after resampling, on every rank."""
         r, i = divmod(int(best), self.P)

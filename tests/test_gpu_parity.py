@@ -841,3 +841,66 @@ def test_sharded_per_particle_maps_need_the_library_communicator():
             h.resample(capi.draw_uniform(3, P * world), both.data_ptr(), True)
     finally:
         h.close()
+
+
+def test_async_resample_pipeline_equals_the_blocking_calls():
+    """pf_resample_async / pf_resample_result: the results of step i read after step i+1 has been
+    enqueued must be the ones the blocking pf_resample returns, step by step, the slots included;
+    the final state is the same; the queue is two deep and says so."""
+    import torch
+    P, M, dims, steps = 6000, 500, (96, 96, 64), 6
+    sc = synth.scene(dims, P, M, seed=61)
+    u = capi.draw_uniform(17, P)
+    upd = capi.UpdateParams(10, 100, -3, 0, 3.0)
+    tp = sc["true_pose"]
+    pos = tp[:3].copy(); zyx = np.array([tp[3], 0.0, 0.0])
+    rng = np.random.default_rng(61)
+    hosts = [(tp[0] + rng.normal(0, 0.03, P), tp[1] + rng.normal(0, 0.03, P), tp[2] + rng.normal(0, 0.015, P),
+              tp[3] + rng.normal(0, 0.02, P)) for _ in range(steps)]
+    runs = []
+    for mode in ("blocking", "async"):
+        h = capi.Handle(_shared_cfg(P, dims, order_mode=capi.PF_ORDER_FAST))
+        try:
+            blocks = []
+            for xs in hosts:                                   # pose blocks resident in HBM, as bench.py does
+                h.predict(*xs); h.synchronize(); blocks.append(h.poses_tensor().clone())
+            torch.cuda.synchronize()
+            h.write_map(0, sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+            h.set_beams(*sc["beams"]); h.set_scan(sc["points"], sc["ray_idx"])
+            res = []
+            for i in range(steps):
+                h.measure(0); h.update_map(capi.PF_GRID_SHARED, upd, pos, zyx)
+                h.predict_device(blocks[i].data_ptr()); h.weights()
+                if mode == "blocking":
+                    res.append(h.resample(u if i == 0 else None))
+                else:
+                    h.resample_async(u if i == 0 else None, None, True)
+                    if i:
+                        res.append(h.resample_result())
+            if mode == "async":
+                with pytest.raises(capi.PfError, match="outstanding|waits"):
+                    h.resample(None)                           # one still in flight
+                res.append(h.resample_result())
+                with pytest.raises(capi.PfError, match="no resample outstanding"):
+                    h.resample_result()
+            runs.append((res, h.get_weights(), np.stack(h.get_poses()), h.read_map(0)))
+        finally:
+            h.close()
+    (ra, wa, pa, ma), (rb, wb, pb, mb) = runs
+    assert len(ra) == len(rb) == steps
+    for a, b in zip(ra, rb):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    assert np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1])
+    assert np.array_equal(pa, pb) and np.array_equal(ma, mb)
+    # the queue is two deep
+    h = capi.Handle(_shared_cfg(P, dims, order_mode=capi.PF_ORDER_FAST))
+    try:
+        h.write_map(0, sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"]); h.set_beams(*sc["beams"])
+        for i in range(2):
+            h.measure(0); h.weights(); h.resample_async(u if i == 0 else None)
+        h.measure(0); h.weights()
+        with pytest.raises(capi.PfError, match="two resamples"):
+            h.resample_async(None)
+        h.resample_result(); h.resample_result()
+    finally:
+        h.close()

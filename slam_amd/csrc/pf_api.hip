@@ -68,7 +68,7 @@ struct pf_handle {
     int ring_first_run = 1;
     char* vote_scratch = nullptr;      // pf_scan_vote's device scratch, grown on demand
     size_t vote_cap = 0;
-    int32_t* bmin = nullptr;           // [ceil(P/256)] block minima of scores (pfk_reduce_scores)
+    int32_t* bmin = nullptr;           // [ceil(P/64)] block minima of scores (pfk_reduce_scores)
     int32_t* draw = nullptr;           // [Pg]
     int32_t* first = nullptr;          // [Pg]
     int32_t* dup_anc = nullptr;        // [Pg]
@@ -420,7 +420,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     if (const char* e = getenv("SLAM_PF_EXACT_MEASURE")) h->force_exact_measure = atoi(e);
     CREATE_TRY(dalloc(&h->partial, (size_t)h->max_chunks * P));
     CREATE_TRY(dalloc(&h->scores, P));
-    CREATE_TRY(dalloc(&h->bmin, (P + 255) / 256));
+    CREATE_TRY(dalloc(&h->bmin, (P + 63) / 64));
     CREATE_TRY(dalloc(&h->draw, Pg));
     CREATE_TRY(dalloc(&h->first, Pg));
     CREATE_TRY(dalloc(&h->dup_anc, Pg));

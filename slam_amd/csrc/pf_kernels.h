@@ -91,7 +91,7 @@ hipError_t pfk_measure_col(hipStream_t st, const double* sorted, int P, const ui
                            PfSwz sw, const PfColG* cg, const int group_ends[4], int n_chunks,
                            PfGridParams gp, double lmax, const int32_t* order, int2* partial);
 hipError_t pfk_swz_build(hipStream_t st, const uint8_t* lin, uint8_t* shadow, PfSwz sw);
-// bmin: int32 [ceil(P/256)], the smallest sum_match of each 256-particle block
+// bmin: int32 [ceil(P/64)], the smallest sum_match of each 64-particle block
 // zero_a / zero_b: n_zero int32 each set to zero (the ordering's counters), n_zero may be 0
 hipError_t pfk_reduce_scores(hipStream_t st, const int2* partial, int n_chunks, int P, int2* scores,
                              int32_t* bmin, int32_t* zero_a, int32_t* zero_b, int n_zero);
@@ -114,7 +114,8 @@ struct PfResampleScratch {
 
 // K3: S3P:920-937. w in/out [Pg]; logw out [Pg]; cdf out [Pg+1]; scratch double [Pg+1].
 // Also initialises K4's first[Pg] table and counters[0..2] for this step.
-// bmin (may be null): pfk_reduce_scores' block minima of exactly these scores; saves the min pass.
+// bmin (may be null): pfk_reduce_scores' ceil(Pg/64) block minima of exactly these scores; saves the
+// min pass.
 hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
                        double* cdf, double* scratch, bool exact, int32_t* first,
                        unsigned long long* counters, PfResampleScratch sc, const int32_t* bmin);

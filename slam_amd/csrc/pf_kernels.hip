@@ -515,32 +515,38 @@ __global__ __launch_bounds__(256) void k_swz_build(const uint8_t* __restrict__ l
 }
 static unsigned swz_build_threads(PfSwz sw) { return (sw.gz + 3u) / 4u * sw.gx * sw.gy; }
 
+// One workgroup per 64 particles: wave q adds the chunks k = q, q+4, ... (a dozen independent loads
+// per lane, all in flight), wave 0 adds the four partial sums. Integer sums: any order.
 __global__ __launch_bounds__(256) void k_reduce_scores(const int2* __restrict__ partial,
                                                        int n_chunks, int P,
                                                        int2* __restrict__ scores,
                                                        int32_t* __restrict__ bmin,
                                                        int32_t* __restrict__ zero_a,
                                                        int32_t* __restrict__ zero_b, int n_zero) {
-    __shared__ int sh[4];
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    __shared__ int2 sh[3][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
     // the ordering's 4096-bucket counters are consumed by now (it ran before K1): leave them zero
-    for (int k = p; k < n_zero; k += gridDim.x * 256) { zero_a[k] = 0; zero_b[k] = 0; }
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n_zero; k += gridDim.x * 256) { zero_a[k] = 0; zero_b[k] = 0; }
     int sx = 0, sy = 0;
     if (p < P) {
-#pragma unroll 8
-        for (int k = 0; k < n_chunks; ++k) {
+#pragma unroll 16
+        for (int k = q; k < n_chunks; k += 4) {
             const int2 v = partial[(size_t)k * P + p];
             sx += v.x; sy += v.y;
         }
-        scores[p] = make_int2(sx, sy);
     }
+    if (q) sh[q - 1][lane] = make_int2(sx, sy);
+    __syncthreads();
+    if (q) return;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { sx += sh[r][lane].x; sy += sh[r][lane].y; }
+    if (p < P) scores[p] = make_int2(sx, sy);
     // the block's smallest sum_match: K3 starts from these instead of a pass of its own (S3P:920-925)
     int m = p < P ? sx : 0x7fffffff;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) bmin[blockIdx.x] = min(min(sh[0], sh[1]), min(sh[2], sh[3]));
+    if (lane == 0) bmin[blockIdx.x] = m;
 }
 
 __global__ __launch_bounds__(256) void k_voxel_indices(const double* __restrict__ pose, int P,
@@ -698,7 +704,7 @@ __global__ __launch_bounds__(256) void k_order_scatter_s(const int32_t* __restri
                                                          int32_t* cursor, int32_t* __restrict__ order,
                                                          const double* __restrict__ pose,
                                                          double* __restrict__ sorted) {
-    __shared__ int off[4096];
+    __shared__ int off[4096], lc[4096];
     __shared__ int tot[4];
     const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6;
     int4 v[4];
@@ -726,11 +732,22 @@ __global__ __launch_bounds__(256) void k_order_scatter_s(const int32_t* __restri
         o.w = run; run += v[k].w;
         ((int4*)off)[lt * 4 + k] = o;
     }
+    // position inside the bucket in two levels: rank among this workgroup's particles of the key
+    // (LDS), then one global add per key and workgroup for the workgroup's base. Resampled clouds
+    // put hundreds of particles into the same few buckets; one returning global atomic each on
+    // the same address was most of this kernel's time.
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lc[lt + 256 * k] = 0;
     __syncthreads();
     const int i = blockIdx.x * 256 + lt;
+    const int key = i < P ? keys[i] : 0;
+    int rank = -1;
+    if (i < P) rank = atomicAdd(&lc[key], 1);
+    __syncthreads();
+    if (rank == 0) lc[key] = atomicAdd(&cursor[key], lc[key]);   // the only reader and writer of lc[key] here
+    __syncthreads();
     if (i >= P) return;
-    const int key = keys[i];
-    const int r = off[key] + atomicAdd(&cursor[key], 1);
+    const int r = off[key] + lc[key] + rank;
     order[r] = i;
 #pragma unroll
     for (int k = 0; k < 5; ++k) sorted[(size_t)k * P + r] = pose[(size_t)(4 + k) * P + i];
@@ -757,7 +774,7 @@ hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, i
 hipError_t pfk_reduce_scores(hipStream_t st, const int2* partial, int n_chunks, int P,
                              int2* scores, int32_t* bmin, int32_t* zero_a, int32_t* zero_b,
                              int n_zero) {
-    hipLaunchKernelGGL(k_reduce_scores, dim3((P + 255) / 256), dim3(256), 0, st, partial,
+    hipLaunchKernelGGL(k_reduce_scores, dim3((P + 63) / 64), dim3(256), 0, st, partial,
                        n_chunks, P, scores, bmin, zero_a, zero_b, n_zero);
     return hipGetLastError();
 }

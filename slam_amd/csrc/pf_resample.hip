@@ -627,7 +627,8 @@ template <bool POSE>
 __device__ inline void d4_apply(int vb, int lt, double* sv4, int* si4, int32_t* slot_anc,
                                 const int32_t* dup_anc, int Pg, double* w, float* logw, double* pose,
                                 double* bbest_v, int32_t* bbest_i, int32_t* order_hist = nullptr,
-                                int32_t* order_keys = nullptr, PfOrderParams op = PfOrderParams{}) {
+                                int32_t* order_keys = nullptr, PfOrderParams op = PfOrderParams{},
+                                int* lds_hist = nullptr) {
     const int g = vb * NB + lt, lane = lt & 63, wv4 = lt >> 6;
     double v = 0.0;
     int idx = -1;
@@ -639,7 +640,8 @@ __device__ inline void d4_apply(int vb, int lt, double* sv4, int* si4, int32_t* 
             // lane order now (the first stage of pfk_order)
             const int key = order_key(pose, Pg, a, op);
             order_keys[g] = key;
-            atomicAdd(&order_hist[key], 1);
+            if (lds_hist) atomicAdd(&lds_hist[key], 1);     // flushed by the caller, one add per key and workgroup
+            else atomicAdd(&order_hist[key], 1);
         }
         v = w[a];
         if (a != g) {
@@ -677,8 +679,26 @@ __global__ __launch_bounds__(NB) void k4_apply(int32_t* __restrict__ slot_anc,
                                                PfOrderParams op) {
     __shared__ double sv[NB / WAVE];
     __shared__ int si[NB / WAVE];
+    // the key counts go through a workgroup-private histogram: a resampled cloud puts hundreds of
+    // slots into the same few buckets, and that many global adds on one address serialise
+    __shared__ int lh[POSE ? 4096 : 1];
+    const bool count = POSE && order_hist;                  // 4096-bucket keys only (pf_api.hip)
+    if (count) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lh[(threadIdx.x + NB * k) & (POSE ? 4095 : 0)] = 0;
+        __syncthreads();
+    }
     d4_apply<POSE>(blockIdx.x, threadIdx.x, sv, si, slot_anc, dup_anc, Pg, w, logw, pose, bbest_v, bbest_i,
-                   order_hist, order_keys, op);
+                   order_hist, order_keys, op, count ? lh : nullptr);
+    if (count) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int b = (threadIdx.x + NB * k) & (POSE ? 4095 : 0);
+            const int c = lh[b];
+            if (c) atomicAdd(&order_hist[b], c);
+        }
+    }
 }
 // host_out (may be null): pinned host memory the last stage of K4 writes the step's results to
 // ({no-hit draws, ambiguous draws, no-hit draws after the re-search, best}); the stream
@@ -693,19 +713,20 @@ __device__ inline void d4_argmax(int nb, const double* bbest_v, const int32_t* b
         const int oi = bbest_i[k]; const double ov = bbest_v[k];
         if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
     }
-    __syncthreads();
-    sv[tid] = v; si[tid] = idx;
-    __syncthreads();
-    for (int o = WG / 2; o > 0; o >>= 1) {
-        if (tid < o) {
-            const double ov = sv[tid + o]; const int oi = si[tid + o];
-            if (oi >= 0 && (si[tid] < 0 || ov > sv[tid] || (ov == sv[tid] && oi < si[tid]))) {
-                sv[tid] = ov; si[tid] = oi;
-            }
-        }
-        __syncthreads();
+    // larger value wins, ties go to the lower index: associative and commutative, any tree will do
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_down(v, o, WAVE);
+        const int oi = __shfl_down(idx, o, WAVE);
+        if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
     }
+    __syncthreads();
+    if ((tid & 63) == 0) { sv[tid >> 6] = v; si[tid >> 6] = idx; }
+    __syncthreads();
     if (tid == 0) {
+        for (int k = 1; k < WG / WAVE; ++k)
+            if (si[k] >= 0 && (idx < 0 || sv[k] > v || (sv[k] == v && si[k] < idx))) { v = sv[k]; idx = si[k]; }
+        si[0] = idx;
         int b = *best_inout;
         if (si[0] >= 0) *best_inout = b = si[0];            // otherwise the previous index stays
         if (host_out) {
@@ -833,7 +854,7 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
         return hipGetLastError();
     }
     if (bmin && !chain_only()) {
-        hipLaunchKernelGGL(k3_raw_m, dim3(nb), dim3(NB), 0, st, scores, Pg, w, scratch, bmin, nb, sc.bsum,
+        hipLaunchKernelGGL(k3_raw_m, dim3(nb), dim3(NB), 0, st, scores, Pg, w, scratch, bmin, (Pg + 63) / 64, sc.bsum,
                            sc.bmax, sc.bse);
     } else {
         hipLaunchKernelGGL(k3_min, dim3(1), dim3(WG), 0, st, scores, Pg, sc.prm);

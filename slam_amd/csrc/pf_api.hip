@@ -77,8 +77,10 @@ struct pf_handle {
     int32_t* best = nullptr;           // inside `counters`' allocation: one D2H copy returns all
     // pinned host memory K4's last kernel writes {counters[3], best} to: two slots, so that one
     // resample may be in flight while the next step is enqueued (pf_resample_async / _result)
-    unsigned long long* h_result = nullptr;    // [2][4]
+    unsigned long long* h_result = nullptr;    // [2] slots of result_slot_u64 words (pfk_result_slot_bytes)
     unsigned long long* d_result = nullptr;    // the same memory as the device sees it
+    size_t result_slot_u64 = 0;
+    int32_t best_prev = 0;                     // S3P:756: index_high_weight, kept when no weight is above 0
     hipEvent_t rs_event[2] = {nullptr, nullptr};   // recorded behind each slot's resample
     unsigned long long rs_issued = 0, rs_done = 0; // resamples enqueued / results handed out
     unsigned long long* counters = nullptr;   // [3]
@@ -428,7 +430,9 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->slot_anc, Pg));
     CREATE_TRY(dalloc(&h->counters, 4));            // [0..2] counters, [3] holds `best`
     h->best = (int32_t*)(h->counters + 3);
-    CREATE_TRY(hipHostMalloc((void**)&h->h_result, 8 * sizeof(unsigned long long), hipHostMallocMapped));
+    h->result_slot_u64 = pfk_result_slot_bytes(h->Pg) / sizeof(unsigned long long);
+    CREATE_TRY(hipHostMalloc((void**)&h->h_result, 2 * pfk_result_slot_bytes(h->Pg), hipHostMallocMapped));
+    memset(h->h_result, 0, 2 * pfk_result_slot_bytes(h->Pg));
     CREATE_TRY(hipHostGetDevicePointer((void**)&h->d_result, h->h_result, 0));
     CREATE_TRY(hipEventCreateWithFlags(&h->rs_event[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->rs_event[1], hipEventDisableTiming));
@@ -853,7 +857,7 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
         HIP_TRY(h, pfk_resample(h->stream, h->cdf, h->u, h->Pg, h->P, h->offset, bound, h->w, h->logw,
                                 h->pose, (const double*)poses_global_dev, h->slab ? h->maps : nullptr,
                                 h->slab, (unsigned long long)h->elements, h->draw, h->first, h->dup_anc,
-                                h->free_slot, h->slot_anc, h->best, h->counters, h->rs, h->d_result + 4 * slot,
+                                h->free_slot, h->slot_anc, h->best, h->counters, h->rs, h->d_result + h->result_slot_u64 * slot,
                                 count_keys ? h->order_hist[0] : nullptr, h->order_keys, op));
         h->hist_counted = count_keys;
     }
@@ -914,9 +918,10 @@ int pf_resample_result(pf_handle* h, int32_t* best_out, int64_t* nohit_out, int6
     const int slot = (int)(h->rs_done & 1ull);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipEventSynchronize(h->rs_event[slot]));
-    const unsigned long long* r = h->h_result + 4 * slot;
+    const unsigned long long* r = h->h_result + h->result_slot_u64 * slot;
     const unsigned long long cnt[3] = {r[0], r[1], r[2]};
-    if (best_out) *best_out = (int32_t)(r[3] & 0xffffffffull);
+    h->best_prev = pfk_result_best(r, h->best_prev);
+    if (best_out) *best_out = h->best_prev;
     if (nohit_out) *nohit_out = (int64_t)(cnt[1] ? cnt[2] : cnt[0]);
     if (ambiguous_out) *ambiguous_out = (int64_t)cnt[1];
     ++h->rs_done;

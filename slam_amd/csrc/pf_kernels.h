@@ -124,7 +124,12 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
 // ambiguous draws on the sequential-order CDF when bound > 0), slot assignment, permutation of
 // weights / pose rows / map slabs, arg-max. counters: unsigned long long [3] = {no-hit draws,
 // ambiguous draws, no-hit draws after the re-search}. host_out: device-visible pinned host
-// memory, unsigned long long [4], receives {counters[0..2], best} from the last kernel.
+// memory, one result slot (PF_RESULT_HEADER unsigned long long, then double [nb] and int32 [nb],
+// nb = ceil(Pg/256)). The default form leaves the last stage of the arg-max to the host: the
+// fill kernel writes every 256-particle block's best weight and index into the slot and
+// {counters[0..2], PF_RESULT_BLOCKS | nb} into its header (pfk_result_best reads them); the
+// one-stage-per-launch and one-workgroup forms end with the arg-max kernel, which writes
+// {counters[0..2], best}.
 // order_hist/order_keys (may be null): the one-GPU fill stage also counts K1's lane-order keys of
 // the poses it leaves behind (pfk_order's first stage, saved for the next pf_measure).
 hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int Pg, int P,
@@ -135,6 +140,15 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
                         unsigned long long* counters, PfResampleScratch sc,
                         unsigned long long* host_out, int32_t* order_hist, int32_t* order_keys,
                         PfOrderParams op);
+
+#define PF_RESULT_HEADER 4
+#define PF_RESULT_BLOCKS (1ull << 63)
+static inline size_t pfk_result_slot_bytes(int Pg) {
+    const size_t nb = ((size_t)Pg + 255) / 256;
+    return (PF_RESULT_HEADER * sizeof(unsigned long long) + nb * (sizeof(double) + sizeof(int32_t)) + 63) & ~(size_t)63;
+}
+// S3P:814-820 from a finished result slot (host memory): first strict maximum above 0, else prev.
+int32_t pfk_result_best(const unsigned long long* slot, int32_t prev);
 
 // K5: S3P:628-704. rot9: row-major ZYX matrix from the host libm. wpts: double [M][3] scratch.
 struct PfUpdateParams {

@@ -670,13 +670,21 @@ __device__ inline void d4_apply(int vb, int lt, double* sv4, int* si4, int32_t* 
         bbest_i[vb] = idx;
     }
 }
+// host_hdr (may be null): the header of a pinned result slot; bbest_v / bbest_i then point into
+// the same slot and the host finishes the arg-max (pfk_result_best).
 template <bool POSE>
 __global__ __launch_bounds__(NB) void k4_apply(int32_t* __restrict__ slot_anc,
                                                const int32_t* __restrict__ dup_anc, int Pg,
                                                double* w, float* logw, double* pose,
                                                double* bbest_v, int32_t* bbest_i,
                                                int32_t* order_hist, int32_t* order_keys,
-                                               PfOrderParams op) {
+                                               PfOrderParams op, const unsigned long long* counters,
+                                               unsigned long long* host_hdr) {
+    if (host_hdr && blockIdx.x == 0 && threadIdx.x == 0) {
+        host_hdr[0] = ld_agent(&counters[0]); host_hdr[1] = ld_agent(&counters[1]);
+        host_hdr[2] = ld_agent(&counters[2]);
+        host_hdr[3] = PF_RESULT_BLOCKS | (unsigned long long)gridDim.x;
+    }
     __shared__ double sv[NB / WAVE];
     __shared__ int si[NB / WAVE];
     // the key counts go through a workgroup-private histogram: a resampled cloud puts hundreds of
@@ -908,12 +916,17 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
         hipLaunchKernelGGL(k4_scatter, dim3(nb), dim3(NB), 0, st, draw, Pg, first, sc.boff2, dup_anc,
                            free_slot, slot_anc);
     }
+    // default form: the blocks' bests go straight into the pinned result slot, no arg-max launch
+    const bool host_argmax = folded && host_out;
+    double* bv = host_argmax ? (double*)(host_out + PF_RESULT_HEADER) : sc.bbest_v;
+    int32_t* bi = host_argmax ? (int32_t*)(bv + nb) : sc.bbest_i;
+    unsigned long long* hdr = host_argmax ? host_out : nullptr;
     if (P == Pg && !pose_gathered) {
         hipLaunchKernelGGL(k4_apply<true>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
-                           pose, sc.bbest_v, sc.bbest_i, order_hist, order_keys, op);
+                           pose, bv, bi, order_hist, order_keys, op, counters, hdr);
     } else {
         hipLaunchKernelGGL(k4_apply<false>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
-                           pose, sc.bbest_v, sc.bbest_i, nullptr, nullptr, op);
+                           pose, bv, bi, nullptr, nullptr, op, counters, hdr);
         hipLaunchKernelGGL(k_apply_pose, dim3(nblocks(P)), dim3(NB), 0, st, slot_anc, P, offset, pose,
                            pose_gathered);
     }
@@ -925,7 +938,19 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
         hipLaunchKernelGGL(k_apply_maps, dim3(P, gy), dim3(NB), 0, st, slot_anc, P, offset, maps,
                            map_stride, map_bytes);
     }
-    hipLaunchKernelGGL(k4_argmax, dim3(1), dim3(WG), 0, st, nb, sc.bbest_v, sc.bbest_i, best, counters,
-                       host_out);
+    if (!host_argmax)
+        hipLaunchKernelGGL(k4_argmax, dim3(1), dim3(WG), 0, st, nb, sc.bbest_v, sc.bbest_i, best, counters,
+                           host_out);
     return hipGetLastError();
+}
+
+int32_t pfk_result_best(const unsigned long long* slot, int32_t prev) {
+    if (!(slot[3] & PF_RESULT_BLOCKS)) return (int32_t)(slot[3] & 0xffffffffull);   // the arg-max kernel ran
+    const size_t nb = (size_t)(slot[3] & 0xffffffffull);
+    const double* bv = (const double*)(slot + PF_RESULT_HEADER);
+    const int32_t* bi = (const int32_t*)(bv + nb);
+    double v = 0.0; int32_t idx = -1;
+    for (size_t k = 0; k < nb; ++k)                         // blocks ascend in index: ties keep the earlier one
+        if (bi[k] >= 0 && (idx < 0 || bv[k] > v)) { v = bv[k]; idx = bi[k]; }
+    return idx >= 0 ? idx : prev;                           // S3P:816: nothing above 0 keeps the previous index
 }

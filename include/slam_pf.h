@@ -99,9 +99,12 @@ const char* pf_last_error(const pf_handle* h);
 int pf_predict(pf_handle* h, const double* x, const double* y, const double* z, const double* yaw);
 /* The same for a caller whose poses already live on this GPU: pose_block_dev is a device
  * pointer to a block laid out like pf_poses_device() (double [9][n_particles]: x, y, z, yaw,
- * cos, sin, x/res, y/res, z/res), e.g. one that an earlier pf_predict produced. Copied on the
- * handle's stream, no host work. Rows 4..8 must be the host-libm values of rows 0..3 for the
- * results to match the reference bit for bit. */
+ * cos, sin, x/res, y/res, z/res), e.g. one that an earlier pf_predict produced. No host work.
+ * On a handle that holds all particles the block is not copied: the next pf_resample reads
+ * the rows from it while it writes the handle's own poses (any other call that needs the
+ * poses copies them first), so the block must stay unchanged until that work has run on the
+ * handle's stream; a sharded handle copies it at once. Rows 4..8 must be the host-libm values
+ * of rows 0..3 for the results to match the reference bit for bit. */
 int pf_predict_device(pf_handle* h, const void* pose_block_dev);
 int pf_get_poses(pf_handle* h, double* x, double* y, double* z, double* yaw);
 /* weight vector of ALL n_particles_global particles (S3P:51; every rank holds the whole vector) */

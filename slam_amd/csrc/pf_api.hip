@@ -35,6 +35,10 @@ struct pf_handle {
     long long local_elements = 0;
     // device state
     double* pose = nullptr;            // [9][P]
+    // one GPU: pf_predict_device only remembers the caller's block; the fill stage of the next
+    // resample reads the rows from there while it writes `pose` (a 720 KB copy and a launch less
+    // per step). Any other reader of `pose` makes the copy first (materialize_pose).
+    const double* pose_src = nullptr;
     double* w = nullptr;               // [Pg]
     float* logw = nullptr;             // [Pg]
     double* cdf = nullptr;             // [Pg+1]
@@ -240,6 +244,14 @@ struct Timed {
         h->ev[id].push_back(ep);
     }
 };
+
+hipError_t materialize_pose(pf_handle* h) {
+    if (!h->pose_src) return hipSuccess;
+    const double* src = h->pose_src;
+    h->pose_src = nullptr;
+    return hipMemcpyAsync(h->pose, src, sizeof(double) * PF_POSE_ROWS * (size_t)h->P, hipMemcpyDeviceToDevice,
+                          h->stream);
+}
 
 // Makes h->stream wait for the shared-grid update still running on the side stream.
 hipError_t wait_map_writes(pf_handle* h) {
@@ -491,6 +503,7 @@ int pf_predict(pf_handle* h, const double* x, const double* y, const double* z, 
             return fail(h, PF_ERR_ARG, "pf_predict: particle %d pose not finite or |pos/res| >= 2^24", i);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));             // staging buffer reuse
+    h->pose_src = nullptr;
     upload_pose_rows(h, x, y, z, yaw);
     HIP_TRY(h, hipMemcpyAsync(h->pose, h->h_pose.data(), sizeof(double) * PF_POSE_ROWS * h->P,
                               hipMemcpyHostToDevice, h->stream));
@@ -504,8 +517,13 @@ int pf_predict_device(pf_handle* h, const void* pose_block_dev) {
     if (!h) return PF_ERR_ARG;
     NEED(h, pose_block_dev, "null pose block");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    HIP_TRY(h, hipMemcpyAsync(h->pose, pose_block_dev, sizeof(double) * PF_POSE_ROWS * h->P,
-                              hipMemcpyDeviceToDevice, h->stream));
+    if (h->P == h->Pg) {
+        h->pose_src = (const double*)pose_block_dev;  // read in place by the next pf_resample, copied on any other use
+    } else {
+        h->pose_src = nullptr;
+        HIP_TRY(h, hipMemcpyAsync(h->pose, pose_block_dev, sizeof(double) * PF_POSE_ROWS * h->P,
+                                  hipMemcpyDeviceToDevice, h->stream));
+    }
     HIP_TRY(h, drop_counted_keys(h));
     h->order_dirty = true;
     h->poses_gathered = false;
@@ -516,6 +534,7 @@ int pf_get_poses(pf_handle* h, double* x, double* y, double* z, double* yaw) {
     if (!h) return PF_ERR_ARG;
     NEED(h, x && y && z && yaw, "null pose array");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, materialize_pose(h));
     const size_t n = sizeof(double) * (size_t)h->P;
     double* dst[4] = {x, y, z, yaw};
     for (int k = 0; k < 4; ++k)
@@ -696,6 +715,7 @@ int pf_measure(pf_handle* h, int add_points) {
     if (!h) return PF_ERR_ARG;
     const bool fuse = add_points != 0 && h->cfg.map_mode == PF_MAP_PER_PARTICLE;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, materialize_pose(h));
     // Without fuse only the occupied beams matter (S3P:886) and beams may be split over
     // blockIdx.y; with fuse every beam is walked in order by one lane.
     const int Mk = fuse ? h->M : h->M_occ;
@@ -772,7 +792,11 @@ int pf_get_scores(pf_handle* h, int32_t* sum, int32_t* cnt) {
 }
 
 void* pf_scores_device(pf_handle* h) { return h ? (void*)h->scores : nullptr; }
-void* pf_poses_device(pf_handle* h) { return h ? (void*)h->pose : nullptr; }
+void* pf_poses_device(pf_handle* h) {
+    if (!h) return nullptr;
+    if (h->pose_src && (hipSetDevice(h->cfg.device) != hipSuccess || materialize_pose(h) != hipSuccess)) return nullptr;
+    return (void*)h->pose;
+}
 void* pf_stream(pf_handle* h) { return h ? (void*)h->stream : nullptr; }
 
 int pf_voxel_indices(pf_handle* h, int32_t i, int32_t* flat_out) {
@@ -780,6 +804,7 @@ int pf_voxel_indices(pf_handle* h, int32_t i, int32_t* flat_out) {
     NEED(h, i >= 0 && i < h->P, "particle index");
     NEED(h, flat_out || h->M == 0, "null output");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, materialize_pose(h));
     HIP_TRY(h, pfk_voxel_indices(h->stream, h->pose, h->P, i, h->beams, h->M, grid_params(h), h->vox));
     if (h->M)
         HIP_TRY(h, hipMemcpyAsync(flat_out, h->vox, sizeof(int32_t) * (size_t)h->M, hipMemcpyDeviceToHost, h->stream));
@@ -840,6 +865,7 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
         poses_global_dev = h->poses_all;
     }
     h->poses_gathered = false;
+    if (poses_global_dev) HIP_TRY(h, materialize_pose(h));   // kept slots stay where they are in h->pose
     if (u) {
         HIP_TRY(h, hipMemcpyAsync(h->u, u, sizeof(double) * (size_t)h->Pg, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -855,11 +881,12 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
         const PfOrderParams op = order_params(h);
         const bool count_keys = h->P == h->Pg && !poses_global_dev && op.mode != 0 && op.bits == 4;
         HIP_TRY(h, pfk_resample(h->stream, h->cdf, h->u, h->Pg, h->P, h->offset, bound, h->w, h->logw,
-                                h->pose, (const double*)poses_global_dev, h->slab ? h->maps : nullptr,
+                                h->pose, h->pose_src, (const double*)poses_global_dev, h->slab ? h->maps : nullptr,
                                 h->slab, (unsigned long long)h->elements, h->draw, h->first, h->dup_anc,
                                 h->free_slot, h->slot_anc, h->best, h->counters, h->rs, h->d_result + h->result_slot_u64 * slot,
                                 count_keys ? h->order_hist[0] : nullptr, h->order_keys, op));
         h->hist_counted = count_keys;
+        h->pose_src = nullptr;                        // every row is in h->pose now
     }
     if (slot_anc_out)
         HIP_TRY(h, hipMemcpyAsync(slot_anc_out, h->slot_anc, sizeof(int32_t) * (size_t)h->Pg,

@@ -132,9 +132,11 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
 // {counters[0..2], best}.
 // order_hist/order_keys (may be null): the one-GPU fill stage also counts K1's lane-order keys of
 // the poses it leaves behind (pfk_order's first stage, saved for the next pf_measure).
+// pose_src (one GPU; may be null = pose): where the predicted pose rows are read from; every slot's
+// row is then written into pose, so a caller's block can stand in for a copy into pose.
 hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int Pg, int P,
                         int offset, double bound, double* w, float* logw, double* pose,
-                        const double* pose_gathered, uint8_t* maps, unsigned long long map_stride,
+                        const double* pose_src, const double* pose_gathered, uint8_t* maps, unsigned long long map_stride,
                         unsigned long long map_bytes, int32_t* draw, int32_t* first,
                         int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
                         unsigned long long* counters, PfResampleScratch sc,

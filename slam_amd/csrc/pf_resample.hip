@@ -626,6 +626,7 @@ __global__ __launch_bounds__(NB) void k_first_c(double* cdf, const double* __res
 template <bool POSE>
 __device__ inline void d4_apply(int vb, int lt, double* sv4, int* si4, int32_t* slot_anc,
                                 const int32_t* dup_anc, int Pg, double* w, float* logw, double* pose,
+                                const double* pose_src,
                                 double* bbest_v, int32_t* bbest_i, int32_t* order_hist = nullptr,
                                 int32_t* order_keys = nullptr, PfOrderParams op = PfOrderParams{},
                                 int* lds_hist = nullptr) {
@@ -638,18 +639,18 @@ __device__ inline void d4_apply(int vb, int lt, double* sv4, int* si4, int32_t* 
         if (POSE && order_hist) {
             // slot g ends this step with its ancestor's pose: count its key for the next K1's
             // lane order now (the first stage of pfk_order)
-            const int key = order_key(pose, Pg, a, op);
+            const int key = order_key(pose_src, Pg, a, op);
             order_keys[g] = key;
             if (lds_hist) atomicAdd(&lds_hist[key], 1);     // flushed by the caller, one add per key and workgroup
             else atomicAdd(&order_hist[key], 1);
         }
         v = w[a];
-        if (a != g) {
-            w[g] = v; logw[g] = logw[a];
-            if (POSE) {
+        if (a != g) { w[g] = v; logw[g] = logw[a]; }
+        // pose_src != pose: the predicted poses still sit in the caller's block (pf_predict_device
+        // did not copy them); every slot takes its ancestor's row from there
+        if (POSE && (a != g || pose_src != pose)) {
 #pragma unroll
-                for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * Pg + g] = pose[(size_t)k * Pg + a];
-            }
+            for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * Pg + g] = pose_src[(size_t)k * Pg + a];
         }
         if (v > 0.0) idx = g; else v = 0.0;                 // NaN and <= 0 never win (S3P:816)
     }
@@ -676,6 +677,7 @@ template <bool POSE>
 __global__ __launch_bounds__(NB) void k4_apply(int32_t* __restrict__ slot_anc,
                                                const int32_t* __restrict__ dup_anc, int Pg,
                                                double* w, float* logw, double* pose,
+                                               const double* pose_src,
                                                double* bbest_v, int32_t* bbest_i,
                                                int32_t* order_hist, int32_t* order_keys,
                                                PfOrderParams op, const unsigned long long* counters,
@@ -696,8 +698,8 @@ __global__ __launch_bounds__(NB) void k4_apply(int32_t* __restrict__ slot_anc,
         for (int k = 0; k < 16; ++k) lh[(threadIdx.x + NB * k) & (POSE ? 4095 : 0)] = 0;
         __syncthreads();
     }
-    d4_apply<POSE>(blockIdx.x, threadIdx.x, sv, si, slot_anc, dup_anc, Pg, w, logw, pose, bbest_v, bbest_i,
-                   order_hist, order_keys, op, count ? lh : nullptr);
+    d4_apply<POSE>(blockIdx.x, threadIdx.x, sv, si, slot_anc, dup_anc, Pg, w, logw, pose, pose_src, bbest_v,
+                   bbest_i, order_hist, order_keys, op, count ? lh : nullptr);
     if (count) {
         __syncthreads();
 #pragma unroll
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(WG) void k4_mid(double* cdf, const double* __restri
         d4_scatter(vb0 + grp, lt, sd + 4 * grp, sf + 4 * grp, draw, Pg, first, sc.boff2, dup_anc, slot_anc);
     __syncthreads();
     for (int vb0 = 0; vb0 < nb; vb0 += WG / NB)
-        d4_apply<true>(vb0 + grp, lt, sv + 4 * grp, sd + 4 * grp, slot_anc, dup_anc, Pg, w, logw, pose,
+        d4_apply<true>(vb0 + grp, lt, sv + 4 * grp, sd + 4 * grp, slot_anc, dup_anc, Pg, w, logw, pose, pose,
                        sc.bbest_v, sc.bbest_i, order_hist, order_keys, op);
     __syncthreads();
     d4_argmax(nb, sc.bbest_v, sc.bbest_i, best, tile, (int*)(tile + WG), counters, host_out);
@@ -883,7 +885,7 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
 // counters: unsigned long long [3] = {nohit, ambiguous, nohit after the re-search}.
 hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int Pg, int P,
                         int offset, double bound, double* w, float* logw, double* pose,
-                        const double* pose_gathered, uint8_t* maps, unsigned long long map_stride,
+                        const double* pose_src, const double* pose_gathered, uint8_t* maps, unsigned long long map_stride,
                         unsigned long long map_bytes, int32_t* draw, int32_t* first,
                         int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
                         unsigned long long* counters, PfResampleScratch sc,
@@ -891,7 +893,10 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
                         PfOrderParams op) {
     const int nb = nblocks(Pg);
     // counters[0..2] and first[] were initialised by the weight kernels of this step
+    if (!pose_src) pose_src = pose;
     if (mid_ok(Pg) && P == Pg && !pose_gathered && !(maps && map_stride)) {
+        if (pose_src != pose)
+            (void)hipMemcpyAsync(pose, pose_src, sizeof(double) * PF_POSE_ROWS * (size_t)P, hipMemcpyDeviceToDevice, st);
         hipLaunchKernelGGL(k4_mid, dim3(1), dim3(WG), 0, st, (double*)cdf, u, Pg, bound, w, logw, pose,
                            draw, first, dup_anc, slot_anc, best, counters, sc, host_out, order_hist,
                            order_keys, op);
@@ -923,10 +928,10 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
     unsigned long long* hdr = host_argmax ? host_out : nullptr;
     if (P == Pg && !pose_gathered) {
         hipLaunchKernelGGL(k4_apply<true>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
-                           pose, bv, bi, order_hist, order_keys, op, counters, hdr);
+                           pose, pose_src, bv, bi, order_hist, order_keys, op, counters, hdr);
     } else {
         hipLaunchKernelGGL(k4_apply<false>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
-                           pose, bv, bi, nullptr, nullptr, op, counters, hdr);
+                           pose, pose, bv, bi, nullptr, nullptr, op, counters, hdr);
         hipLaunchKernelGGL(k_apply_pose, dim3(nblocks(P)), dim3(NB), 0, st, slot_anc, P, offset, pose,
                            pose_gathered);
     }

@@ -517,7 +517,7 @@ int pf_predict_device(pf_handle* h, const void* pose_block_dev) {
     if (!h) return PF_ERR_ARG;
     NEED(h, pose_block_dev, "null pose block");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (h->P == h->Pg) {
+    if (h->P == h->Pg && !h->comm) {
         h->pose_src = (const double*)pose_block_dev;  // read in place by the next pf_resample, copied on any other use
     } else {
         h->pose_src = nullptr;
@@ -822,6 +822,7 @@ int pf_weights(pf_handle* h, const void* scores_global_dev) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const int2* sc = scores_global_dev ? (const int2*)scores_global_dev : h->scores;
     if (!scores_global_dev && h->comm) {              // C1: 8 B per particle, rank order
+        HIP_TRY(h, materialize_pose(h));
         const bool both = h->group_gathers && rccl().GroupStart && rccl().GroupEnd;
         ncclResult_t r = both ? rccl().GroupStart() : ncclSuccess;
         if (r == ncclSuccess)
@@ -857,6 +858,7 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
                                    "inside the library: pf_comm_init first");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (!poses_global_dev && h->comm) {               // C2: the 72-B pose blocks, rank order
+        HIP_TRY(h, materialize_pose(h));
         if (!h->poses_gathered) {                     // (else pf_weights' group already brought them)
             const ncclResult_t r = rccl().AllGather(h->pose, h->poses_all, PF_POSE_ROWS * (size_t)h->P,
                                                     ncclFloat64, h->comm, h->stream);
@@ -879,7 +881,8 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
         const double bound = h->exact ? 0.0 : 8.0 * (double)h->Pg * 1.1102230246251565e-16;
         // one GPU, shared-key ordering: the fill stage leaves K1's order keys of the new poses
         const PfOrderParams op = order_params(h);
-        const bool count_keys = h->P == h->Pg && !poses_global_dev && op.mode != 0 && op.bits == 4;
+        // (sharded: the kernel that writes the local shard's rows counts them)
+        const bool count_keys = op.mode != 0 && op.bits == 4;
         HIP_TRY(h, pfk_resample(h->stream, h->cdf, h->u, h->Pg, h->P, h->offset, bound, h->w, h->logw,
                                 h->pose, h->pose_src, (const double*)poses_global_dev, h->slab ? h->maps : nullptr,
                                 h->slab, (unsigned long long)h->elements, h->draw, h->first, h->dup_anc,

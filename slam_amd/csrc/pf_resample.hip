@@ -794,23 +794,52 @@ __global__ __launch_bounds__(WG) void k4_mid(double* cdf, const double* __restri
     d4_argmax(nb, sc.bbest_v, sc.bbest_i, best, tile, (int*)(tile + WG), counters, host_out);
 }
 
+// The local shard's pose rows after the resample, and (order_hist != null: 4096-bucket keys) the
+// count of K1's lane-order keys of those poses through a workgroup-private histogram, as the
+// one-GPU fill stage does: the next pf_measure then needs no key pass of its own.
 __global__ __launch_bounds__(NB) void k_apply_pose(const int32_t* __restrict__ slot_anc, int P,
                                                    int offset, double* pose,
-                                                   const double* __restrict__ gathered) {
+                                                   const double* __restrict__ gathered,
+                                                   int32_t* order_hist, int32_t* order_keys,
+                                                   PfOrderParams op) {
+    __shared__ int lh[4096];
+    if (order_hist) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lh[threadIdx.x + NB * k] = 0;
+        __syncthreads();
+    }
     const int i = blockIdx.x * NB + threadIdx.x;
-    if (i >= P) return;
-    const int g = offset + i;
-    const int a = slot_anc[g];
-    if (a == g) return;
-    if (gathered) {
-        const int r = a / P, ai = a - r * P;
-        const double* src = gathered + (size_t)r * PF_POSE_ROWS * P;
+    if (i < P) {
+        const int g = offset + i;
+        const int a = slot_anc[g];
+        const double* src = pose;                           // rows of the ancestor: [9][P] block
+        int ai = i;
+        if (a != g) {
+            if (gathered) {
+                const int r = a / P;
+                ai = a - r * P;
+                src = gathered + (size_t)r * PF_POSE_ROWS * P;
+            } else {
+                ai = a - offset;
+            }
+        }
+        if (order_hist) {
+            const int key = order_key(src, P, ai, op);
+            order_keys[i] = key;
+            atomicAdd(&lh[key], 1);
+        }
+        if (a != g) {
 #pragma unroll
-        for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * P + i] = src[(size_t)k * P + ai];
-    } else {
-        const int ai = a - offset;
+            for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * P + i] = src[(size_t)k * P + ai];
+        }
+    }
+    if (order_hist) {
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * P + i] = pose[(size_t)k * P + ai];
+        for (int k = 0; k < 16; ++k) {
+            const int b = threadIdx.x + NB * k, c = lh[b];
+            if (c) atomicAdd(&order_hist[b], c);
+        }
     }
 }
 // Per-particle map slabs (S3P:810 copies the 7.2 MB map with the struct): 16 B per lane.
@@ -933,7 +962,7 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
         hipLaunchKernelGGL(k4_apply<false>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
                            pose, pose, bv, bi, nullptr, nullptr, op, counters, hdr);
         hipLaunchKernelGGL(k_apply_pose, dim3(nblocks(P)), dim3(NB), 0, st, slot_anc, P, offset, pose,
-                           pose_gathered);
+                           pose_gathered, order_hist, order_keys, op);
     }
     if (maps && map_stride) {
         unsigned long long n16 = (map_bytes + 15) / 16;

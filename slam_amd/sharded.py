@@ -80,6 +80,13 @@ class ShardedBackend:
     def set_scan(self, *a): self.h.set_scan(*a)
     def update_map(self, *a): self.h.update_map(*a)
 
+    def _flush_poses(self):
+        # pf_predict_device may have left a pose block in place (one-GPU handle): pf_poses_device
+        # makes the library copy it into the buffer the cached view points at
+        flush = getattr(self.h, "poses_device", None)
+        if flush is not None:
+            flush()
+
     def _sync_device(self, t):
         if t.is_cuda:
             self.torch.cuda.current_stream(t.device).synchronize()
@@ -105,6 +112,7 @@ class ShardedBackend:
     def resample(self, u=None, want_slots=True):
         if self.native:
             return self.h.resample(u, None, want_slots)   # C2 inside the library
+        self._flush_poses()
         self._before_collective()
         self.dist.all_gather_into_tensor(self._poses_all, self._poses, group=self.group)     # C2
         self._after_collective(self._poses_all)
@@ -113,6 +121,7 @@ class ShardedBackend:
     def resample_async(self, u=None, want_slots=False):
         if self.native:
             return self.h.resample_async(u, None, want_slots)
+        self._flush_poses()
         self._before_collective()
         self.dist.all_gather_into_tensor(self._poses_all, self._poses, group=self.group)     # C2
         self._after_collective(self._poses_all)

@@ -580,6 +580,27 @@ def test_sharded_backend_on_rccl_single_rank():
         for a, b in zip(out[4], out[5]):
             assert np.array_equal(a, b)
         assert not np.array_equal(out[0][4], out[4][4])         # the late predict did change the poses
+        # a pose block handed over on the device (pf_predict_device leaves it in place on a one-GPU
+        # handle) must reach both kinds of all-gather
+        dev = []
+        for sharded in (False, "torch", "native"):
+            h = capi.Handle(_shared_cfg(P, dims))
+            be = ShardedBackend(h, dist, native=sharded == "native") if sharded else h
+            try:
+                h.write_map(0, sc["grid"]); be.predict(x2, sc["y"], sc["z"], sc["yaw"]); h.synchronize()
+                block = h.poses_tensor().clone(); torch.cuda.synchronize()
+                be.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+                be.set_beams(*sc["beams"]); be.measure(0)
+                h.predict_device(block.data_ptr())
+                be.weights()
+                r = be.resample(u)
+                dev.append((r[0], r[1], np.stack(h.get_poses())))
+            finally:
+                h.close()
+        for other in dev[1:]:
+            for a, b in zip(dev[0], other):
+                assert np.array_equal(a, b)
+        assert np.array_equal(np.sort(dev[0][2][0]), np.sort(x2[np.unique(dev[0][0])].repeat(np.unique(dev[0][0], return_counts=True)[1])))
     finally:
         if created:
             dist.destroy_process_group()

@@ -249,13 +249,15 @@ __global__ __launch_bounds__(WG) void k3_min(const int2* __restrict__ scores, in
 // raw weights + per-block partials: bsum[b] = sum of the block's raw weights (wave shuffle tree,
 // then the 4 wave totals in order), (bmax[b], bse[b]) = block max of l and sum of exp(l - bmax).
 // vb = the 256-particle block, lt = thread inside it, sh4 = 4 doubles of LDS for this block.
-__device__ inline void d3_raw(int vb, int lt, double* sh4, const int2* __restrict__ scores, int Pg,
-                              double* w, double* __restrict__ lbuf, const double* prm, double* bsum,
-                              double* bmax, double* bse) {
+// (w0, s0: this thread's previous weight and sum_match, loaded by the caller, which may do so
+// before the constants in prm exist)
+__device__ inline void d3_raw_v(int vb, int lt, double* sh4, double w0, int s0, int Pg,
+                                double* w, double* __restrict__ lbuf, const double* prm, double* bsum,
+                                double* bmax, double* bse) {
     const int g = vb * NB + lt, lane = lt & 63, wv4 = lt >> 6;
     double raw = 0, l = -INFINITY;
     if (g < Pg) {
-        raw_weight(w[g], scores[g].x, prm[PRM_K99], prm[PRM_N], prm[PRM_LOGN], raw, l);
+        raw_weight(w0, s0, prm[PRM_K99], prm[PRM_N], prm[PRM_LOGN], raw, l);
         w[g] = raw;
         lbuf[g] = l;
     }
@@ -263,6 +265,12 @@ __device__ inline void d3_raw(int vb, int lt, double* sh4, const int2* __restric
     const double m = group_max(l, sh4, lane, wv4);
     const double e = group_sum((g < Pg && l > -INFINITY) ? exp(l - m) : 0.0, sh4, lane, wv4);
     if (lt == 0 && g < Pg) { bsum[vb] = s; bmax[vb] = m; bse[vb] = e; }
+}
+__device__ inline void d3_raw(int vb, int lt, double* sh4, const int2* __restrict__ scores, int Pg,
+                              double* w, double* __restrict__ lbuf, const double* prm, double* bsum,
+                              double* bmax, double* bse) {
+    const int g = vb * NB + lt;
+    d3_raw_v(vb, lt, sh4, g < Pg ? w[g] : 0.0, g < Pg ? scores[g].x : 0, Pg, w, lbuf, prm, bsum, bmax, bse);
 }
 __global__ __launch_bounds__(NB) void k3_raw(const int2* __restrict__ scores, int Pg, double* w,
                                              double* __restrict__ lbuf,
@@ -283,6 +291,10 @@ __global__ __launch_bounds__(NB) void k3_raw_m(const int2* __restrict__ scores, 
     __shared__ int shi[NB / WAVE];
     __shared__ double prm_s[8];
     const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6;
+    // this thread's inputs first: their latency overlaps the reduction of the block minima
+    const int g0 = blockIdx.x * NB + lt;
+    const double w0 = g0 < Pg ? w[g0] : 0.0;
+    const int s0 = g0 < Pg ? scores[g0].x : 0;
     int m = INT_MAX;
     for (int k = lt; k < n_bmin; k += NB) m = min(m, bmin[k]);
     m = wave_min_i(m);
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(NB) void k3_raw_m(const int2* __restrict__ scores, 
         prm_s[PRM_LOGN] = log(n_match);
     }
     __syncthreads();
-    d3_raw(blockIdx.x, lt, sh, scores, Pg, w, lbuf, prm_s, bsum, bmax, bse);
+    d3_raw_v(blockIdx.x, lt, sh, w0, s0, Pg, w, lbuf, prm_s, bsum, bmax, bse);
 }
 
 // One workgroup: S = sum of bsum (thread t adds blocks t, t+1024, ... then the fixed tree),
@@ -342,13 +354,13 @@ __global__ __launch_bounds__(WG) void k3_combine(int nb, const double* __restric
 }
 
 // normalise, log-weights, CDF: cdf[i+1] = (boff[block] + inclusive scan of raw inside the block) / S.
-__device__ inline void d3_norm(int vb, int lt, double* sh4, int Pg, double* w, const double* lbuf,
-                               float* __restrict__ logw, const double* prm, const double* boff,
-                               double* cdf, int32_t* __restrict__ first,
-                               unsigned long long* counters) {
+// (raw, lb: this thread's raw weight and log-domain twin, loaded by the caller)
+__device__ inline void d3_norm_v(int vb, int lt, double* sh4, int Pg, double raw, double lb, double* w,
+                                 float* __restrict__ logw, const double* prm, const double* boff,
+                                 double* cdf, int32_t* __restrict__ first,
+                                 unsigned long long* counters) {
     const int g = vb * NB + lt, lane = lt & 63, wv4 = lt >> 6;
     const double S = prm[PRM_S];
-    const double raw = g < Pg ? w[g] : 0.0;
     const double inc = wave_scan(raw);
     __syncthreads();
     if (lane == 63) sh4[wv4] = inc;
@@ -357,12 +369,20 @@ __device__ inline void d3_norm(int vb, int lt, double* sh4, int Pg, double* w, c
     for (int k = 0; k < wv4; ++k) woff += sh4[k];
     if (g < Pg) {
         w[g] = raw / S;                                     // S3P:936
-        logw[g] = (float)(lbuf[g] - prm[PRM_LSE]);
+        logw[g] = (float)(lb - prm[PRM_LSE]);
         cdf[g + 1] = (boff[vb] + (woff + inc)) / S;
         first[g] = NEVER_DRAWN;                             // K4's first-occurrence table
     }
     if (g == 0) cdf[0] = 0;
     if (g < 3) counters[g] = 0;                             // K4's counters start at zero
+}
+__device__ inline void d3_norm(int vb, int lt, double* sh4, int Pg, double* w, const double* lbuf,
+                               float* __restrict__ logw, const double* prm, const double* boff,
+                               double* cdf, int32_t* __restrict__ first,
+                               unsigned long long* counters) {
+    const int g = vb * NB + lt;
+    d3_norm_v(vb, lt, sh4, Pg, g < Pg ? w[g] : 0.0, g < Pg ? lbuf[g] : 0.0, w, logw, prm, boff, cdf, first,
+              counters);
 }
 __global__ __launch_bounds__(NB) void k3_norm(int Pg, double* w, const double* __restrict__ lbuf,
                                               float* __restrict__ logw,
@@ -388,6 +408,9 @@ __global__ __launch_bounds__(NB) void k3_norm_c(int Pg, int nb, double* w, const
     __shared__ double sh4[NB / WAVE];
     __shared__ double prm_s[8], s_boff;
     const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6, vb = blockIdx.x;
+    // this thread's inputs first: their latency overlaps the combine
+    const int g0 = vb * NB + lt;
+    const double raw0 = g0 < Pg ? w[g0] : 0.0, lb0 = g0 < Pg ? lbuf[g0] : 0.0;
     double loc[4], inc[4];
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
@@ -426,7 +449,7 @@ __global__ __launch_bounds__(NB) void k3_norm_c(int Pg, int nb, double* w, const
         prm_s[PRM_LSE] = gmax + log(se);
     }
     __syncthreads();
-    d3_norm(vb, lt, sh4, Pg, w, lbuf, logw, prm_s, &s_boff - vb, cdf, first, counters);
+    d3_norm_v(vb, lt, sh4, Pg, raw0, lb0, w, logw, prm_s, &s_boff - vb, cdf, first, counters);
 }
 
 // K3 in ONE workgroup for up to PF_MID_MAX particles: the same four stages on the same 256-
@@ -557,13 +580,10 @@ __global__ __launch_bounds__(WG) void k4_scan(int nb, const int2* __restrict__ b
     __shared__ int sd[WG / WAVE], sf[WG / WAVE];
     d4_scan(nb, bcnt, boff, ndup_out, sd, sf);
 }
-__device__ inline void d4_scatter(int vb, int lt, int* sd4, int* sf4, const int32_t* draw, int Pg,
-                                  const int32_t* first, const int2* boff, int32_t* dup_anc,
-                                  int32_t* slot_anc) {
+// (a, isd, isf: this thread's draw and its duplicate / free-slot flags, loaded by the caller)
+__device__ inline void d4_scatter_v(int vb, int lt, int* sd4, int* sf4, int a, int isd, int isf, int Pg,
+                                    const int2* boff, int32_t* dup_anc, int32_t* slot_anc) {
     const int i = vb * NB + lt, lane = lt & 63, wv4 = lt >> 6;
-    const int a = i < Pg ? draw[i] : 0;
-    const int isd = i < Pg && ld_agent(&first[a]) != i;
-    const int isf = i < Pg && ld_agent(&first[i]) == NEVER_DRAWN;
     const unsigned long long md = __ballot(isd), mf = __ballot(isf);
     const unsigned long long below = (1ull << lane) - 1ull;
     __syncthreads();
@@ -576,6 +596,15 @@ __device__ inline void d4_scatter(int vb, int lt, int* sd4, int* sf4, const int3
     // a free slot takes the duplicate of its own rank; the apply stage resolves -1-rank -> dup_anc[rank]
     if (isf) slot_anc[i] = -1 - (of + __popcll(mf & below));
     else slot_anc[i] = i;
+}
+__device__ inline void d4_scatter(int vb, int lt, int* sd4, int* sf4, const int32_t* draw, int Pg,
+                                  const int32_t* first, const int2* boff, int32_t* dup_anc,
+                                  int32_t* slot_anc) {
+    const int i = vb * NB + lt;
+    const int a = i < Pg ? draw[i] : 0;
+    const int isd = i < Pg && ld_agent(&first[a]) != i;
+    const int isf = i < Pg && ld_agent(&first[i]) == NEVER_DRAWN;
+    d4_scatter_v(vb, lt, sd4, sf4, a, isd, isf, Pg, boff, dup_anc, slot_anc);
 }
 __global__ __launch_bounds__(NB) void k4_scatter(const int32_t* __restrict__ draw, int Pg,
                                                  const int32_t* __restrict__ first,
@@ -597,6 +626,11 @@ __global__ __launch_bounds__(NB) void k4_scatter_s(const int32_t* __restrict__ d
     __shared__ int sd[NB / WAVE], sf[NB / WAVE];
     __shared__ int2 my_off;
     const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6, vb = blockIdx.x;
+    // this thread's draw and flags first: their latency overlaps the scan of the block counts
+    const int i0 = vb * NB + lt;
+    const int a0 = i0 < Pg ? draw[i0] : 0;
+    const int isd0 = i0 < Pg && ld_agent(&first[a0]) != i0;
+    const int isf0 = i0 < Pg && ld_agent(&first[i0]) == NEVER_DRAWN;
     int a = 0, b = 0;
     for (int k = lt; k < vb; k += NB) { const int2 c = bcnt[k]; a += c.x; b += c.y; }
 #pragma unroll
@@ -605,7 +639,7 @@ __global__ __launch_bounds__(NB) void k4_scatter_s(const int32_t* __restrict__ d
     __syncthreads();
     if (lt == 0) my_off = make_int2(sd[0] + sd[1] + sd[2] + sd[3], sf[0] + sf[1] + sf[2] + sf[3]);
     __syncthreads();
-    d4_scatter(vb, lt, sd, sf, draw, Pg, first, &my_off - vb, dup_anc, slot_anc);
+    d4_scatter_v(vb, lt, sd, sf, a0, isd0, isf0, Pg, &my_off - vb, dup_anc, slot_anc);
 }
 // k_first with the rare sequential-order CDF inside: when draws were ambiguous every workgroup
 // rebuilds the CDF itself (all write the same values) before it searches again.

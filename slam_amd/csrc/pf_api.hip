@@ -112,15 +112,14 @@ struct pf_handle {
     int n_points = 0, n_rays = 0;
     bool measured = false, weighted = false, have_u = false;
     bool exact = true;
-    // The shared-grid update (K5) depends on nothing K3/K4 produce and nothing but K1, K6 and the
-    // map accessors read what it writes: with SLAM_PF_SIDE=1 it runs on a side stream, after the
-    // map readers already enqueued, and the next map reader waits for it. Off by default: the
-    // two event records and waits per step cost the host more than the overlap gives the GPU
-    // (141.6 vs 127.0 us per step at configs[1]).
-    hipStream_t side = nullptr;
-    hipEvent_t ev_main = nullptr, ev_side = nullptr;
-    bool side_pending = false;
-    bool use_side = false;
+    // The shared-grid update (K5) depends on nothing K3/K4 produce, and nothing but K1, K6 and the
+    // map accessors read what it writes. pf_update_map(PF_GRID_SHARED) therefore only records the
+    // work; the next pf_weights launches it as extra workgroups of its two kernels (pfk_weights'
+    // `carry`), and any call that reads or writes the grid or the scan buffers first runs it on
+    // its own (flush_update). Measured before this: the same update on a side stream lost more to
+    // the cross-stream waits than the overlap gave (104.9 vs 96.5 us per step).
+    PfUpdateWork upd{};
+    bool upd_pending = false;
     // RCCL communicator of a sharded handle (pf_comm_init): the two all-gathers of the step are
     // then enqueued by pf_weights / pf_resample themselves, on the handle's stream
     ncclComm_t comm = nullptr;
@@ -253,12 +252,16 @@ hipError_t materialize_pose(pf_handle* h) {
                           h->stream);
 }
 
-// Makes h->stream wait for the shared-grid update still running on the side stream.
-hipError_t wait_map_writes(pf_handle* h) {
-    if (!h->side_pending) return hipSuccess;
-    h->side_pending = false;
-    return hipStreamWaitEvent(h->stream, h->ev_side, 0);
+// Runs a recorded shared-grid update now, on its own (see pf_handle::upd).
+hipError_t flush_update(pf_handle* h) {
+    if (!h->upd_pending) return hipSuccess;
+    h->upd_pending = false;
+    Timed t(h, PF_K_UPDATE);
+    hipError_t e = pfk_update_hits(h->stream, h->upd);
+    if (e == hipSuccess) e = pfk_update_rays(h->stream, h->upd);
+    return e;
 }
+hipError_t wait_map_writes(pf_handle* h) { return flush_update(h); }
 
 void upload_pose_rows(pf_handle* h, const double* x, const double* y, const double* z,
                       const double* yaw) {
@@ -304,9 +307,6 @@ void pf_destroy(pf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
-    if (h->ev_main) (void)hipEventDestroy(h->ev_main);
-    if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_col,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
                     h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
@@ -392,9 +392,6 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(hipSetDevice(c.device));
     CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
-    CREATE_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    CREATE_TRY(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
     const size_t P = h->P, Pg = h->Pg;
     CREATE_TRY(dalloc(&h->pose, PF_POSE_ROWS * P));
     CREATE_TRY(dalloc(&h->w, Pg));
@@ -426,7 +423,6 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->beams_occ, (size_t)c.max_beams + PF_BEAM_GROUP));
     CREATE_TRY(dalloc(&h->beams_occ_f, (size_t)c.max_beams + PF_BEAM_GROUP));
     CREATE_TRY(dalloc(&h->beams_col, (size_t)c.max_beams + 1));
-    if (const char* e = getenv("SLAM_PF_SIDE")) h->use_side = atoi(e) != 0;
     if (const char* e = getenv("SLAM_PF_TWO_GATHERS")) h->group_gathers = atoi(e) == 0;
     if (const char* e = getenv("SLAM_PF_CHUNKS")) h->tune_chunks = atoi(e);
     if (h->tune_chunks > h->max_chunks) h->max_chunks = h->tune_chunks < 1024 ? h->tune_chunks : 1024;
@@ -837,8 +833,11 @@ int pf_weights(pf_handle* h, const void* scores_global_dev) {
     }
     {
         Timed t(h, PF_K_WEIGHTS);
+        const int32_t* bmin = sc == h->scores && h->P == h->Pg ? h->bmin : nullptr;
+        const bool carry = h->upd_pending && pfk_weights_carries(h->Pg, h->exact, bmin);
         HIP_TRY(h, pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact, h->first,
-                               h->counters, h->rs, sc == h->scores && h->P == h->Pg ? h->bmin : nullptr));
+                               h->counters, h->rs, bmin, carry ? &h->upd : nullptr));
+        if (carry) h->upd_pending = false;
     }
     h->weighted = true;
     return PF_OK;
@@ -1032,23 +1031,18 @@ int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const dou
     up.hit_inc = p->hit_inc; up.hit_clamp = p->hit_clamp;
     up.miss_inc = p->miss_inc; up.miss_clamp = p->miss_clamp;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (target == PF_GRID_SHARED && h->use_side) {
-        // after everything already enqueued on the main stream (the last K1 among it), beside
-        // whatever the caller enqueues next
-        HIP_TRY(h, hipEventRecord(h->ev_main, h->stream));
-        HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_main, 0));
-        {
-            Timed t(h, PF_K_UPDATE, h->side);
-            HIP_TRY(h, pfk_update_hits(h->side, grid, h->points, h->n_points, h->wpts, up));
-            HIP_TRY(h, pfk_update_rays(h->side, grid, h->wpts, h->ray_idx, h->n_rays, up));
-        }
-        HIP_TRY(h, hipEventRecord(h->ev_side, h->side));
-        h->side_pending = true;
+    HIP_TRY(h, flush_update(h));                      // an earlier update that nobody picked up
+    PfUpdateWork uw{};
+    uw.grid = grid; uw.points = h->points; uw.wpts = h->wpts; uw.ray_idx = h->ray_idx;
+    uw.M = h->n_points; uw.R = h->n_rays; uw.up = up;
+    if (target == PF_GRID_SHARED) {                   // rides with the next pf_weights, or runs at the next map access
+        h->upd = uw;
+        h->upd_pending = true;
         return PF_OK;
     }
     Timed t(h, PF_K_UPDATE);
-    HIP_TRY(h, pfk_update_hits(h->stream, grid, h->points, h->n_points, h->wpts, up));
-    HIP_TRY(h, pfk_update_rays(h->stream, grid, h->wpts, h->ray_idx, h->n_rays, up));
+    HIP_TRY(h, pfk_update_hits(h->stream, uw));
+    HIP_TRY(h, pfk_update_rays(h->stream, uw));
     return PF_OK;
 }
 
@@ -1414,9 +1408,8 @@ int pf_comm_init(pf_handle* h, const void* id, int32_t rank, int32_t world) {
 int pf_set_stream(pf_handle* h, void* hip_stream) {
     if (!h) return PF_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, flush_update(h));
     HIP_TRY(h, hipStreamSynchronize(h->stream));            // nothing of ours left on the old one
-    HIP_TRY(h, hipStreamSynchronize(h->side));
-    h->side_pending = false;
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return PF_OK;
 }

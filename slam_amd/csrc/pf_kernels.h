@@ -112,13 +112,18 @@ struct PfResampleScratch {
     int32_t* ndup;      // [1]
 };
 
+struct PfUpdateWork;
 // K3: S3P:920-937. w in/out [Pg]; logw out [Pg]; cdf out [Pg+1]; scratch double [Pg+1].
 // Also initialises K4's first[Pg] table and counters[0..2] for this step.
 // bmin (may be null): pfk_reduce_scores' ceil(Pg/64) block minima of exactly these scores; saves the
 // min pass.
+// carry (may be null; only when pfk_weights_carries(...)): a map update that does not depend on
+// the weights and that nothing else reads until the next map reader: its hits ride as extra
+// workgroups of the raw-weight kernel, its rays as extra workgroups of the normalise kernel
+// (both pairs are latency-bound and small, side by side they take the time of the longer one).
 hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
                        double* cdf, double* scratch, bool exact, int32_t* first,
-                       unsigned long long* counters, PfResampleScratch sc, const int32_t* bmin);
+                       unsigned long long* counters, PfResampleScratch sc, const int32_t* bmin, const PfUpdateWork* carry = nullptr);
 
 // K4: S3P:757-821, the whole chain on the stream, no host round trip: search (+ re-search of
 // ambiguous draws on the sequential-order CDF when bound > 0), slot assignment, permutation of
@@ -165,10 +170,18 @@ struct PfUpdateParams {
     void* shadow;         // gather-layout copy of the shared grid to keep in step, or null
     uint32_t swz_a, swz_b;
 };
-hipError_t pfk_update_hits(hipStream_t st, void* grid, const double* points, int M, double* wpts,
-                           PfUpdateParams up);
-hipError_t pfk_update_rays(hipStream_t st, void* grid, const double* wpts, const int32_t* ray_idx,
-                           int R, PfUpdateParams up);
+// One map update: M points (sensor frame) -> wpts (grid frame) and hits, then R rays.
+struct PfUpdateWork {
+    void* grid;
+    const double* points;   // [M][3]
+    double* wpts;           // [M][3]
+    const int32_t* ray_idx; // [R]
+    int M, R;
+    PfUpdateParams up;
+};
+bool pfk_weights_carries(int Pg, bool exact, const int32_t* bmin);
+hipError_t pfk_update_hits(hipStream_t st, const PfUpdateWork& uw);
+hipError_t pfk_update_rays(hipStream_t st, const PfUpdateWork& uw);
 hipError_t pfk_fill_u8(hipStream_t st, uint8_t* dst, unsigned long long n, int value);
 
 // K6: S3P:328-376. mats: double [n_yaw][9]; trans: double [n_yaw*n_per_yaw][3]; rot: scratch

@@ -4,6 +4,7 @@
 // would move round() across half-voxel boundaries. Where an fma() appears below it is on
 // integer-valued doubles whose exact result is representable, so fusing changes nothing.
 #include "pf_kernels.h"
+#include "pf_device.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -321,23 +322,6 @@ __global__ __launch_bounds__(256) void k_measure_fast(
 // flat-only bounds test S3P:882 lets indices alias into the neighbouring row), re-does those
 // beams with the reference fp64 sequence, and turns the flat index back into the cell it names.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c) {   // a*b + c, a, b < 2^24
-    unsigned r;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
-    return r;
-}
-// ((X>>2)*a + (Y>>2)*b + (Z>>2)*64) | (X&3)<<4 | (Y&3)<<2 | (Z&3); a, b multiples of 64
-__device__ __forceinline__ unsigned swz_col_base(unsigned X, unsigned Y, unsigned a, unsigned b) {
-    return mad_u24(X >> 2, a, mad_u24(Y >> 2, b, ((X & 3u) << 4) | ((Y & 3u) << 2)));
-}
-__device__ __forceinline__ unsigned swz_col_addr(unsigned base, unsigned Z, unsigned b) {
-    (void)b;
-    return (((Z & ~3u) << 4) + base) | (Z & 3u);
-}
-__device__ __forceinline__ unsigned swz_addr(unsigned X, unsigned Y, unsigned Z, unsigned a, unsigned b) {
-    return swz_col_addr(swz_col_base(X, Y, a, b), Z, b);
-}
-
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int cvt_floor_i32(float x) {       // (int)floorf(x) in one instruction
     int r;
@@ -794,92 +778,11 @@ hipError_t pfk_voxel_indices(hipStream_t st, const double* pose, int P, int i,
 // reproduces the reference's sequential loop exactly. Hits complete (kernel boundary) before
 // the ray march starts, as in S3P:632-661 then S3P:668-704.
 // ------------------------------------------------------------------------------------------
-// Returns false when the cell was already at its clamp for this touch (nothing written).
-__device__ inline bool cell_touch(void* grid, long long f, int inc, int clampv, bool hit,
-                                  bool is_signed) {
-    unsigned* wp = (unsigned*)grid + (f >> 2);
-    const unsigned shft = (unsigned)(f & 3) * 8u;
-    unsigned old = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (true) {
-        const unsigned byte = (old >> shft) & 0xffu;
-        const int v = is_signed ? (int)(int8_t)byte : (int)byte;
-        int nv = v + inc;
-        if (hit ? nv > clampv : nv < clampv) nv = clampv;
-        if (nv == v) return false;
-        const unsigned nw = (old & ~(0xffu << shft)) | (((unsigned)nv & 0xffu) << shft);
-        const unsigned seen = atomicCAS(wp, old, nw);
-        if (seen == old) return true;
-        old = seen;
-    }
+__global__ __launch_bounds__(256) void k_update_hits(PfUpdateWork uw) {
+    d5_hits(blockIdx.x * 256 + threadIdx.x, uw);
 }
-
-// S3P:641-645: per-axis round, int flat index, flat-only bounds. Coordinates are validated on
-// the host to stay far inside int32, so the double arithmetic below is exact.
-__device__ inline long long flat_of(double rx, double ry, double rz, const PfUpdateParams& up) {
-    const double X = round(rx), Y = round(ry), Z = round(rz);
-    if (!(fabs(X) < 2147483648.0 && fabs(Y) < 2147483648.0 && fabs(Z) < 2147483648.0)) return -1;
-    const long long f = (long long)X * up.gy * up.gz + (long long)Y * up.gz + (long long)Z;
-    return (f < 0 || f >= up.elements) ? -1 : f;
-}
-
-// the same touch on the gather-layout copy of the shared grid (both copies see the same
-// order-independent function, so they stay identical)
-__device__ inline void shadow_touch(const PfUpdateParams& up, long long f, int inc, int clampv,
-                                    bool hit) {
-    if (!up.shadow) return;
-    const unsigned fu = (unsigned)f, gyz = (unsigned)(up.gy * up.gz);
-    const unsigned xc = fu / gyz, r = fu - xc * gyz, yc = r / (unsigned)up.gz;
-    const unsigned zc = r - yc * (unsigned)up.gz;
-    cell_touch(up.shadow, (long long)swz_addr(xc, yc, zc, up.swz_a, up.swz_b), inc, clampv, hit, false);
-}
-
-__global__ __launch_bounds__(256) void k_update_hits(void* grid, const double* __restrict__ points,
-                                                     int M, double* __restrict__ wpts,
-                                                     PfUpdateParams up) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    const double px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1],
-                 pz = points[3 * (size_t)i + 2];
-    // S3P:547-549 then S3P:555-557
-    const double wx = (up.rot[0] * px + up.rot[1] * py + up.rot[2] * pz) + up.pos[0];
-    const double wy = (up.rot[3] * px + up.rot[4] * py + up.rot[5] * pz) + up.pos[1];
-    const double wz = (up.rot[6] * px + up.rot[7] * py + up.rot[8] * pz) + up.pos[2];
-    wpts[3 * (size_t)i] = wx; wpts[3 * (size_t)i + 1] = wy; wpts[3 * (size_t)i + 2] = wz;
-    const double dx = wx - up.pos[0], dy = wy - up.pos[1], dz = wz - up.pos[2];
-    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);        // S3P:615-617
-    if (nrm > up.max_range) return;                              // S3P:637 (NaN falls through)
-    const long long f = flat_of(wx * up.conv, wy * up.conv, wz * up.conv, up);
-    if (f < 0) return;
-    // a touch that found the cell saturated in one copy finds it saturated in the other: the two
-    // copies receive the same touches, and within a phase a saturated cell stays saturated
-    if (cell_touch(grid, f, up.hit_inc, up.hit_clamp, true, up.is_signed != 0))
-        shadow_touch(up, f, up.hit_inc, up.hit_clamp, true);
-}
-
-// One wave per ray; lane l takes steps j = 1+l, 65+l, ... (S3P:685: j = 1 .. n_it-1).
-__global__ __launch_bounds__(256) void k_update_rays(void* grid, const double* __restrict__ wpts,
-                                                     const int32_t* __restrict__ ray_idx, int R,
-                                                     PfUpdateParams up) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= R) return;
-    const int lane = threadIdx.x & 63;
-    const double* e = wpts + 3 * (size_t)ray_idx[r];
-    const double dx = e[0] - up.pos[0], dy = e[1] - up.pos[1], dz = e[2] - up.pos[2];
-    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
-    const double nc = nrm * up.conv;
-    const double rr = round(nc);                                 // S3P:676
-    if (!(rr < 2147483648.0)) return;                            // also drops NaN
-    const int n_it = (int)rr;
-    const double sx = dx / nc, sy = dy / nc, sz = dz / nc;       // S3P:681-683
-    for (int j = 1 + lane; j < n_it; j += WAVE) {
-        const double jd = (double)j;
-        const long long f = flat_of((up.pos[0] + sx * jd) * up.conv, (up.pos[1] + sy * jd) * up.conv,
-                                    (up.pos[2] + sz * jd) * up.conv, up);   // S3P:687-690
-        if (f >= 0) {
-            if (cell_touch(grid, f, up.miss_inc, up.miss_clamp, false, up.is_signed != 0))
-                shadow_touch(up, f, up.miss_inc, up.miss_clamp, false);
-        }
-    }
+__global__ __launch_bounds__(256) void k_update_rays(PfUpdateWork uw) {
+    d5_rays(blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, uw);
 }
 
 __global__ __launch_bounds__(256) void k_fill_u8(uint4* dst, unsigned long long n16, uint4 v) {
@@ -888,18 +791,14 @@ __global__ __launch_bounds__(256) void k_fill_u8(uint4* dst, unsigned long long 
         dst[k] = v;
 }
 
-hipError_t pfk_update_hits(hipStream_t st, void* grid, const double* points, int M, double* wpts,
-                           PfUpdateParams up) {
-    if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_update_hits, dim3((M + 255) / 256), dim3(256), 0, st, grid, points, M,
-                       wpts, up);
+hipError_t pfk_update_hits(hipStream_t st, const PfUpdateWork& uw) {
+    if (uw.M == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_update_hits, dim3((uw.M + 255) / 256), dim3(256), 0, st, uw);
     return hipGetLastError();
 }
-hipError_t pfk_update_rays(hipStream_t st, void* grid, const double* wpts, const int32_t* ray_idx,
-                           int R, PfUpdateParams up) {
-    if (R == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_update_rays, dim3((R + 3) / 4), dim3(256), 0, st, grid, wpts, ray_idx, R,
-                       up);
+hipError_t pfk_update_rays(hipStream_t st, const PfUpdateWork& uw) {
+    if (uw.R == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_update_rays, dim3((uw.R + 3) / 4), dim3(256), 0, st, uw);
     return hipGetLastError();
 }
 hipError_t pfk_fill_u8(hipStream_t st, uint8_t* dst, unsigned long long n, int value) {

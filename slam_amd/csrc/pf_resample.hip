@@ -12,6 +12,7 @@
 //         only; k_search counts the draws that fall within that error of a CDF boundary and
 //         the host re-settles them on the sequential-order CDF (k_cdf_exact_if).
 #include "pf_kernels.h"
+#include "pf_device.h"
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(NB) void k3_raw(const int2* __restrict__ scores, in
 // k3_raw with the min stage inside: the smallest sum comes from pfk_reduce_scores' block minima
 // (integers: any order), the three derived constants are computed by every workgroup with the
 // expressions of d3_min.
-__global__ __launch_bounds__(NB) void k3_raw_m(const int2* __restrict__ scores, int Pg, double* w,
+__device__ __forceinline__ void d3_raw_m(int vb, const int2* __restrict__ scores, int Pg, double* w,
                                                double* __restrict__ lbuf,
                                                const int32_t* __restrict__ bmin, int n_bmin,
                                                double* bsum, double* bmax, double* bse) {
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(NB) void k3_raw_m(const int2* __restrict__ scores, 
     __shared__ double prm_s[8];
     const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6;
     // this thread's inputs first: their latency overlaps the reduction of the block minima
-    const int g0 = blockIdx.x * NB + lt;
+    const int g0 = vb * NB + lt;
     const double w0 = g0 < Pg ? w[g0] : 0.0;
     const int s0 = g0 < Pg ? scores[g0].x : 0;
     int m = INT_MAX;
@@ -311,7 +312,25 @@ __global__ __launch_bounds__(NB) void k3_raw_m(const int2* __restrict__ scores, 
         prm_s[PRM_LOGN] = log(n_match);
     }
     __syncthreads();
-    d3_raw_v(blockIdx.x, lt, sh, w0, s0, Pg, w, lbuf, prm_s, bsum, bmax, bse);
+    d3_raw_v(vb, lt, sh, w0, s0, Pg, w, lbuf, prm_s, bsum, bmax, bse);
+}
+
+__global__ __launch_bounds__(NB) void k3_raw_m(const int2* __restrict__ scores, int Pg, double* w,
+                                               double* __restrict__ lbuf,
+                                               const int32_t* __restrict__ bmin, int n_bmin,
+                                               double* bsum, double* bmax, double* bse) {
+    d3_raw_m(blockIdx.x, scores, Pg, w, lbuf, bmin, n_bmin, bsum, bmax, bse);
+}
+// The same launch carrying the hit phase of a map update in workgroups nb .. (S3P:632-661): the
+// two have nothing to do with each other, which is the point: both are a few dependent memory
+// round trips on a handful of CUs, and side by side they take the time of the longer one.
+__global__ __launch_bounds__(NB) void k3_raw_m_u(const int2* __restrict__ scores, int Pg, double* w,
+                                                 double* __restrict__ lbuf,
+                                                 const int32_t* __restrict__ bmin, int n_bmin,
+                                                 double* bsum, double* bmax, double* bse, int nb,
+                                                 PfUpdateWork uw) {
+    if ((int)blockIdx.x >= nb) { d5_hits(((int)blockIdx.x - nb) * NB + (int)threadIdx.x, uw); return; }
+    d3_raw_m(blockIdx.x, scores, Pg, w, lbuf, bmin, n_bmin, bsum, bmax, bse);
 }
 
 // One workgroup: S = sum of bsum (thread t adds blocks t, t+1024, ... then the fixed tree),
@@ -399,7 +418,7 @@ __global__ __launch_bounds__(NB) void k3_norm(int Pg, double* w, const double* _
 // (a launch boundary costs ~4 us here, the redundant scan well under one). The 256 threads walk
 // the 16 wave-shaped pieces of k3_combine's 1024-thread arithmetic in four passes, same
 // shuffles, same order of the wave totals: bit-identical to the separate kernel.
-__global__ __launch_bounds__(NB) void k3_norm_c(int Pg, int nb, double* w, const double* lbuf,
+__device__ __forceinline__ void d3_norm_c(int vb, int Pg, int nb, double* w, const double* lbuf,
                                                 float* __restrict__ logw, const double* bsum,
                                                 const double* bmax, const double* bse, double* cdf,
                                                 int32_t* __restrict__ first,
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(NB) void k3_norm_c(int Pg, int nb, double* w, const
     __shared__ double shT[WG / WAVE], shM[WG / WAVE], shS[WG / WAVE];
     __shared__ double sh4[NB / WAVE];
     __shared__ double prm_s[8], s_boff;
-    const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6, vb = blockIdx.x;
+    const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6;
     // this thread's inputs first: their latency overlaps the combine
     const int g0 = vb * NB + lt;
     const double raw0 = g0 < Pg ? w[g0] : 0.0, lb0 = g0 < Pg ? lbuf[g0] : 0.0;
@@ -450,6 +469,26 @@ __global__ __launch_bounds__(NB) void k3_norm_c(int Pg, int nb, double* w, const
     }
     __syncthreads();
     d3_norm_v(vb, lt, sh4, Pg, raw0, lb0, w, logw, prm_s, &s_boff - vb, cdf, first, counters);
+}
+__global__ __launch_bounds__(NB) void k3_norm_c(int Pg, int nb, double* w, const double* lbuf,
+                                                float* __restrict__ logw, const double* bsum,
+                                                const double* bmax, const double* bse, double* cdf,
+                                                int32_t* __restrict__ first,
+                                                unsigned long long* counters) {
+    d3_norm_c(blockIdx.x, Pg, nb, w, lbuf, logw, bsum, bmax, bse, cdf, first, counters);
+}
+// The same launch carrying the ray phase of the map update (S3P:664-704) in workgroups nb ..,
+// four rays each; the hits rode with the launch before, so they are complete.
+__global__ __launch_bounds__(NB) void k3_norm_c_u(int Pg, int nb, double* w, const double* lbuf,
+                                                  float* __restrict__ logw, const double* bsum,
+                                                  const double* bmax, const double* bse, double* cdf,
+                                                  int32_t* __restrict__ first,
+                                                  unsigned long long* counters, PfUpdateWork uw) {
+    if ((int)blockIdx.x >= nb) {
+        d5_rays(((int)blockIdx.x - nb) * 4 + ((int)threadIdx.x >> 6), (int)threadIdx.x & 63, uw);
+        return;
+    }
+    d3_norm_c(blockIdx.x, Pg, nb, w, lbuf, logw, bsum, bmax, bse, cdf, first, counters);
 }
 
 // K3 in ONE workgroup for up to PF_MID_MAX particles: the same four stages on the same 256-
@@ -912,9 +951,21 @@ static inline bool mid_ok(int Pg) {
     return Pg <= PF_MID_MAX && e && atoi(e) != 0;
 }
 
+bool pfk_weights_carries(int Pg, bool exact, const int32_t* bmin) {
+    return !exact && !mid_ok(Pg) && bmin && !chain_only() && nblocks(Pg) <= WG;
+}
 hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
                        double* cdf, double* scratch, bool exact, int32_t* first,
-                       unsigned long long* counters, PfResampleScratch sc, const int32_t* bmin) {
+                       unsigned long long* counters, PfResampleScratch sc, const int32_t* bmin,
+                       const PfUpdateWork* carry) {
+    if (carry && pfk_weights_carries(Pg, exact, bmin)) {
+        const int nb = nblocks(Pg);
+        hipLaunchKernelGGL(k3_raw_m_u, dim3(nb + (carry->M + NB - 1) / NB), dim3(NB), 0, st, scores, Pg, w, scratch,
+                           bmin, (Pg + 63) / 64, sc.bsum, sc.bmax, sc.bse, nb, *carry);
+        hipLaunchKernelGGL(k3_norm_c_u, dim3(nb + (carry->R + 3) / 4), dim3(NB), 0, st, Pg, nb, w, scratch, logw,
+                           sc.bsum, sc.bmax, sc.bse, cdf, first, counters, *carry);
+        return hipGetLastError();
+    }
     if (exact) {
         hipLaunchKernelGGL(k_weights_exact, dim3(1), dim3(WG), 0, st, scores, Pg, w, logw, cdf, scratch,
                            first, counters);

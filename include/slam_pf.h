@@ -172,7 +172,11 @@ void* pf_poses_device(pf_handle* h);
 int pf_set_scan(pf_handle* h, const double* points, int64_t n_points,
                 const int32_t* ray_idx, int64_t n_rays);
 /* K5: hits then ray march on `target`. pos: sensor position in the grid frame (metres),
- * zyx: angles (S3P:628-631). */
+ * zyx: angles (S3P:628-631). On PF_GRID_SHARED the work is recorded and enqueued by whichever
+ * comes first: the next pf_weights (it rides in that call's launches) or the next call that
+ * reads or writes the grid or the scan (pf_measure, pf_read_map, pf_read_occupied,
+ * pf_scan_vote, pf_ring_*, pf_set_scan, pf_write_map ..., pf_synchronize): every such call
+ * sees the updated grid, as if the update had run here. */
 int pf_update_map(pf_handle* h, int target, const pf_update_params* p,
                   const double pos[3], const double zyx[3]);
 int pf_write_local_map(pf_handle* h, const int8_t* src);

@@ -281,6 +281,16 @@ __global__ __launch_bounds__(NB) void k3_raw(const int2* __restrict__ scores, in
     d3_raw(blockIdx.x, threadIdx.x, sh, scores, Pg, w, lbuf, prm, bsum, bmax, bse);
 }
 
+// (sharded handles: no block minima, k3_min ran before; the hit phase of a map update rides here)
+__global__ __launch_bounds__(NB) void k3_raw_u(const int2* __restrict__ scores, int Pg, double* w,
+                                               double* __restrict__ lbuf,
+                                               const double* __restrict__ prm, double* bsum,
+                                               double* bmax, double* bse, int nb, PfUpdateWork uw) {
+    __shared__ double sh[NB / WAVE];
+    if ((int)blockIdx.x >= nb) { d5_hits(((int)blockIdx.x - nb) * NB + (int)threadIdx.x, uw); return; }
+    d3_raw(blockIdx.x, threadIdx.x, sh, scores, Pg, w, lbuf, prm, bsum, bmax, bse);
+}
+
 // k3_raw with the min stage inside: the smallest sum comes from pfk_reduce_scores' block minima
 // (integers: any order), the three derived constants are computed by every workgroup with the
 // expressions of d3_min.
@@ -952,7 +962,8 @@ static inline bool mid_ok(int Pg) {
 }
 
 bool pfk_weights_carries(int Pg, bool exact, const int32_t* bmin) {
-    return !exact && !mid_ok(Pg) && bmin && !chain_only() && nblocks(Pg) <= WG;
+    (void)bmin;
+    return !exact && !mid_ok(Pg) && !chain_only() && nblocks(Pg) <= WG;
 }
 hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
                        double* cdf, double* scratch, bool exact, int32_t* first,
@@ -960,8 +971,14 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
                        const PfUpdateWork* carry) {
     if (carry && pfk_weights_carries(Pg, exact, bmin)) {
         const int nb = nblocks(Pg);
-        hipLaunchKernelGGL(k3_raw_m_u, dim3(nb + (carry->M + NB - 1) / NB), dim3(NB), 0, st, scores, Pg, w, scratch,
-                           bmin, (Pg + 63) / 64, sc.bsum, sc.bmax, sc.bse, nb, *carry);
+        if (bmin) {
+            hipLaunchKernelGGL(k3_raw_m_u, dim3(nb + (carry->M + NB - 1) / NB), dim3(NB), 0, st, scores, Pg, w,
+                               scratch, bmin, (Pg + 63) / 64, sc.bsum, sc.bmax, sc.bse, nb, *carry);
+        } else {
+            hipLaunchKernelGGL(k3_min, dim3(1), dim3(WG), 0, st, scores, Pg, sc.prm);
+            hipLaunchKernelGGL(k3_raw_u, dim3(nb + (carry->M + NB - 1) / NB), dim3(NB), 0, st, scores, Pg, w,
+                               scratch, sc.prm, sc.bsum, sc.bmax, sc.bse, nb, *carry);
+        }
         hipLaunchKernelGGL(k3_norm_c_u, dim3(nb + (carry->R + 3) / 4), dim3(NB), 0, st, Pg, nb, w, scratch, logw,
                            sc.bsum, sc.bmax, sc.bse, cdf, first, counters, *carry);
         return hipGetLastError();

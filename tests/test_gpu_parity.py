@@ -371,6 +371,56 @@ def test_update_map_shared_uint8_matches_oracle():
         h.close()
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_update_carried_by_the_weight_kernels_matches_oracle(world):
+    """pf_update_map(PF_GRID_SHARED) only records the update; pf_weights launches it inside its own
+    two kernels (one-GPU handle: k3_raw_m_u / k3_norm_c_u; shard of a larger job: k3_raw_u). The
+    grid read afterwards, and the next measure on its gather-layout copy, must be the oracle's;
+    a second update recorded before anybody picked up the first must not lose it."""
+    import torch
+    dims = (96, 96, 64)
+    P = 3000
+    sc = synth.scene(dims, P, 400, seed=77)
+    grid = sc["grid"].copy()
+    grid[grid > 100] = 100
+    pts, ray_idx = sc["points"], sc["ray_idx"]
+    tp = sc["true_pose"]
+    pos = tp[:3].copy(); zyx = np.array([tp[3], 0.0, 0.0])
+    prm = (10, 100, -3, 0)
+    ocfg = O.UpdateCfg(dims[0], dims[1], dims[2], 0.05, 0, prm[0], prm[1], prm[2], prm[3], 3.0)
+    want = grid.copy()
+    for _ in range(3):
+        O.update_map(ocfg, want, pos, zyx, pts, ray_idx)
+    cfg = _shared_cfg(P, dims, order_mode=capi.PF_ORDER_FAST)
+    if world > 1:
+        cfg.n_particles_global = P * world
+        cfg.particle_offset = P
+    h = capi.Handle(cfg)
+    try:
+        h.write_map(0, grid); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"]); h.set_beams(*sc["beams"])
+        h.set_scan(pts, ray_idx)
+        upd = capi.UpdateParams(*prm, 3.0)
+        h.measure(0)
+        h.update_map(capi.PF_GRID_SHARED, upd, pos, zyx)      # recorded ...
+        h.update_map(capi.PF_GRID_SHARED, upd, pos, zyx)      # ... run on its own by this one, which is recorded
+        if world > 1:
+            s, c = h.get_scores()
+            both = torch.tensor(np.stack([np.concatenate([s, s]), np.concatenate([c, c])], 1).astype(np.int32),
+                                device="cuda")
+            h.weights(both.data_ptr())                         # carried by k3_raw_u / k3_norm_c_u
+        else:
+            h.weights()                                        # carried by k3_raw_m_u / k3_norm_c_u
+        h.update_map(capi.PF_GRID_SHARED, upd, pos, zyx)      # picked up by the next map reader
+        h.measure(0)
+        s2, c2 = h.get_scores()
+        assert np.array_equal(h.read_map(0).reshape(dims), want)
+        og = O.ref_grid(*dims)
+        es, ec = O.measure(og, sc["x"], sc["y"], sc["z"], sc["yaw"], want.reshape(-1), 0, *sc["beams"], 0)
+        assert np.array_equal(s2, es) and np.array_equal(c2, ec)
+    finally:
+        h.close()
+
+
 def test_measure_sees_map_updates_in_both_layouts():
     """K1 reads a gather-layout copy of the shared grid; K5 keeps it in step with the
     reference-order copy. Measure -> update -> measure -> upload -> measure against the oracle

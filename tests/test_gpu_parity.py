@@ -975,3 +975,36 @@ def test_async_resample_pipeline_equals_the_blocking_calls():
         h.resample_result(); h.resample_result()
     finally:
         h.close()
+
+
+def test_measure_column_groups_of_every_shape():
+    """K1 groups the occupied beams of one local column (k_measure_col, up to four per group, lz
+    sorted inside a group, groups sorted by size): columns of 1 to 9 beams, lz in any order,
+    repeated beams, columns that leave the grid in z for some particles and in x / y for others,
+    beams below the occupancy threshold in between. Scores against the oracle."""
+    dims = (48, 40, 24)
+    P = 700
+    rng = np.random.default_rng(91)
+    grid = rng.integers(0, 101, dims).astype(np.uint8)
+    x = rng.uniform(0.6, dims[0] * 0.05 - 0.6, P); y = rng.uniform(0.6, dims[1] * 0.05 - 0.6, P)
+    z = rng.uniform(0.1, dims[2] * 0.05 - 0.1, P); yaw = rng.uniform(-3.2, 3.2, P)
+    bx, by, bz, bv = [], [], [], []
+    for _ in range(260):
+        cx, cy = int(rng.integers(-14, 15)), int(rng.integers(-14, 15))
+        n = int(rng.integers(1, 10))
+        zs = rng.integers(-14, 15, n)                       # unsorted, may repeat
+        for k, zz in enumerate(zs):
+            bx.append(cx); by.append(cy); bz.append(int(zz))
+            bv.append(50 if (k % 5) else 3)                 # every fifth beam is not occupied (v <= 20)
+    bx = np.array(bx, np.int32); by = np.array(by, np.int32); bz = np.array(bz, np.int32)
+    bv = np.array(bv, np.int8)
+    og = O.ref_grid(*dims)
+    s, c = O.measure(og, x, y, z, yaw, grid.reshape(-1), 0, bx, by, bz, bv, 0)
+    h = capi.Handle(_shared_cfg(P, dims))
+    try:
+        h.write_map(0, grid); h.predict(x, y, z, yaw); h.set_beams(bx, by, bz, bv); h.measure(0)
+        gs, gc = h.get_scores()
+        assert np.array_equal(gs, s) and np.array_equal(gc, c)
+        assert c.min() < c.max()                            # some particles lose beams at the faces
+    finally:
+        h.close()

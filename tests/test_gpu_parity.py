@@ -417,6 +417,18 @@ def test_update_carried_by_the_weight_kernels_matches_oracle(world):
         og = O.ref_grid(*dims)
         es, ec = O.measure(og, sc["x"], sc["y"], sc["z"], sc["yaw"], want.reshape(-1), 0, *sc["beams"], 0)
         assert np.array_equal(s2, es) and np.array_equal(c2, ec)
+        if world == 1:
+            # a carried update followed by the resample and the next measure
+            h.update_map(capi.PF_GRID_SHARED, upd, pos, zyx)
+            h.weights()
+            h.resample(capi.draw_uniform(5, P))
+            O.update_map(ocfg, want, pos, zyx, pts, ray_idx)
+            assert np.array_equal(h.read_map(0).reshape(dims), want)
+            h.measure(0)                                       # the gather-layout copy followed
+            s3, c3 = h.get_scores()
+            px, py, pz, pyaw = h.get_poses()
+            es, ec = O.measure(og, px, py, pz, pyaw, want.reshape(-1), 0, *sc["beams"], 0)
+            assert np.array_equal(s3, es) and np.array_equal(c3, ec)
     finally:
         h.close()
 

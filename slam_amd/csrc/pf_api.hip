@@ -125,6 +125,7 @@ struct pf_handle {
     ncclComm_t comm = nullptr;
     int comm_world = 1;
     int2* scores_all = nullptr;        // [Pg]
+    int32_t* bmin_all = nullptr;       // [world][ceil(P/64)] every rank's block minima (rides in the group)
     // The pose blocks pf_resample needs are final once the caller has predicted, which the
     // reference does before the weights (S3P:911-914 precede S3P:920): pf_weights then issues both
     // all-gathers as one RCCL group (one launch, one latency) and pf_resample finds the blocks
@@ -307,7 +308,7 @@ void pf_destroy(pf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_col,
+    void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->bmin_all, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_col,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
                     h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -513,8 +514,10 @@ int pf_predict_device(pf_handle* h, const void* pose_block_dev) {
     if (!h) return PF_ERR_ARG;
     NEED(h, pose_block_dev, "null pose block");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (h->P == h->Pg && !h->comm) {
-        h->pose_src = (const double*)pose_block_dev;  // read in place by the next pf_resample, copied on any other use
+    if (h->P == h->Pg || h->comm) {
+        // read in place by the next pf_resample (one GPU) or by the library's all-gather (sharded
+        // with a communicator); copied on any other use
+        h->pose_src = (const double*)pose_block_dev;
     } else {
         h->pose_src = nullptr;
         HIP_TRY(h, hipMemcpyAsync(h->pose, pose_block_dev, sizeof(double) * PF_POSE_ROWS * h->P,
@@ -817,26 +820,31 @@ int pf_weights(pf_handle* h, const void* scores_global_dev) {
     }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const int2* sc = scores_global_dev ? (const int2*)scores_global_dev : h->scores;
+    bool gathered_bmin = false;
     if (!scores_global_dev && h->comm) {              // C1: 8 B per particle, rank order
-        HIP_TRY(h, materialize_pose(h));
         const bool both = h->group_gathers && rccl().GroupStart && rccl().GroupEnd;
+        if (!both) HIP_TRY(h, materialize_pose(h));
         ncclResult_t r = both ? rccl().GroupStart() : ncclSuccess;
         if (r == ncclSuccess)
             r = rccl().AllGather(h->scores, h->scores_all, 2 * (size_t)h->P, ncclInt32, h->comm, h->stream);
-        if (r == ncclSuccess && both)                 // C2 rides along: 72 B per particle
-            r = rccl().AllGather(h->pose, h->poses_all, PF_POSE_ROWS * (size_t)h->P, ncclFloat64, h->comm,
-                                 h->stream);
+        if (r == ncclSuccess && both)                 // C2 rides along: 72 B per particle, from wherever the rows are
+            r = rccl().AllGather(h->pose_src ? h->pose_src : h->pose, h->poses_all, PF_POSE_ROWS * (size_t)h->P,
+                                 ncclFloat64, h->comm, h->stream);
+        if (r == ncclSuccess && both)                 // and every rank's block minima of its scores (K3's min)
+            r = rccl().AllGather(h->bmin, h->bmin_all, ((size_t)h->P + 63) / 64, ncclInt32, h->comm, h->stream);
         if (both) { const ncclResult_t e = rccl().GroupEnd(); if (r == ncclSuccess) r = e; }
+        gathered_bmin = both;
         if (r != ncclSuccess) return fail(h, PF_ERR_HIP, "pf_weights: ncclAllGather: %s", rccl().GetErrorString(r));
         h->poses_gathered = both;
         sc = h->scores_all;
     }
     {
         Timed t(h, PF_K_WEIGHTS);
-        const int32_t* bmin = sc == h->scores && h->P == h->Pg ? h->bmin : nullptr;
+        const int32_t* bmin = sc == h->scores && h->P == h->Pg ? h->bmin : gathered_bmin ? h->bmin_all : nullptr;
+        const int n_bmin = gathered_bmin ? h->comm_world * ((h->P + 63) / 64) : 0;
         const bool carry = h->upd_pending && pfk_weights_carries(h->Pg, h->exact, bmin);
         HIP_TRY(h, pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact, h->first,
-                               h->counters, h->rs, bmin, carry ? &h->upd : nullptr));
+                               h->counters, h->rs, bmin, carry ? &h->upd : nullptr, n_bmin));
         if (carry) h->upd_pending = false;
     }
     h->weighted = true;
@@ -857,16 +865,17 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
                                    "inside the library: pf_comm_init first");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (!poses_global_dev && h->comm) {               // C2: the 72-B pose blocks, rank order
-        HIP_TRY(h, materialize_pose(h));
         if (!h->poses_gathered) {                     // (else pf_weights' group already brought them)
-            const ncclResult_t r = rccl().AllGather(h->pose, h->poses_all, PF_POSE_ROWS * (size_t)h->P,
+            const ncclResult_t r = rccl().AllGather(h->pose_src ? h->pose_src : h->pose, h->poses_all,
+                                                    PF_POSE_ROWS * (size_t)h->P,
                                                     ncclFloat64, h->comm, h->stream);
             if (r != ncclSuccess) return fail(h, PF_ERR_HIP, "pf_resample: ncclAllGather: %s", rccl().GetErrorString(r));
         }
         poses_global_dev = h->poses_all;
     }
     h->poses_gathered = false;
-    if (poses_global_dev) HIP_TRY(h, materialize_pose(h));   // kept slots stay where they are in h->pose
+    if (poses_global_dev && poses_global_dev != (const void*)h->poses_all)
+        HIP_TRY(h, materialize_pose(h));              // the caller's gather: kept slots stay where they are in h->pose
     if (u) {
         HIP_TRY(h, hipMemcpyAsync(h->u, u, sizeof(double) * (size_t)h->Pg, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1400,7 +1409,9 @@ int pf_comm_init(pf_handle* h, const void* id, int32_t rank, int32_t world) {
     }
     h->comm_world = world;
     h->comm_rank = rank;
+    HIP_TRY(h, materialize_pose(h));
     HIP_TRY(h, dalloc(&h->scores_all, (size_t)h->Pg));
+    HIP_TRY(h, dalloc(&h->bmin_all, (size_t)world * (((size_t)h->P + 63) / 64)));
     HIP_TRY(h, dalloc(&h->poses_all, PF_POSE_ROWS * (size_t)h->Pg));
     return PF_OK;
 }

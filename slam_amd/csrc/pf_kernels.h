@@ -115,15 +115,15 @@ struct PfResampleScratch {
 struct PfUpdateWork;
 // K3: S3P:920-937. w in/out [Pg]; logw out [Pg]; cdf out [Pg+1]; scratch double [Pg+1].
 // Also initialises K4's first[Pg] table and counters[0..2] for this step.
-// bmin (may be null): pfk_reduce_scores' ceil(Pg/64) block minima of exactly these scores; saves the
-// min pass.
+// bmin (may be null): n_bmin (0: ceil(Pg/64)) block minima of exactly these scores, as
+// pfk_reduce_scores writes them (gathered rank by rank on a sharded handle); saves the min pass.
 // carry (may be null; only when pfk_weights_carries(...)): a map update that does not depend on
 // the weights and that nothing else reads until the next map reader: its hits ride as extra
 // workgroups of the raw-weight kernel, its rays as extra workgroups of the normalise kernel
 // (both pairs are latency-bound and small, side by side they take the time of the longer one).
 hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
                        double* cdf, double* scratch, bool exact, int32_t* first,
-                       unsigned long long* counters, PfResampleScratch sc, const int32_t* bmin, const PfUpdateWork* carry = nullptr);
+                       unsigned long long* counters, PfResampleScratch sc, const int32_t* bmin, const PfUpdateWork* carry = nullptr, int n_bmin = 0);
 
 // K4: S3P:757-821, the whole chain on the stream, no host round trip: search (+ re-search of
 // ambiguous draws on the sequential-order CDF when bound > 0), slot assignment, permutation of
@@ -137,8 +137,9 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
 // {counters[0..2], best}.
 // order_hist/order_keys (may be null): the one-GPU fill stage also counts K1's lane-order keys of
 // the poses it leaves behind (pfk_order's first stage, saved for the next pf_measure).
-// pose_src (one GPU; may be null = pose): where the predicted pose rows are read from; every slot's
-// row is then written into pose, so a caller's block can stand in for a copy into pose.
+// pose_src (may be null = pose): where the predicted pose rows of this handle still are when
+// pf_predict_device left them in the caller's block: every slot's row is then written into pose
+// (one GPU: read from pose_src; sharded: from pose_gathered, which was gathered from pose_src).
 hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int Pg, int P,
                         int offset, double bound, double* w, float* logw, double* pose,
                         const double* pose_src, const double* pose_gathered, uint8_t* maps, unsigned long long map_stride,

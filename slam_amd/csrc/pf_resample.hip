@@ -882,7 +882,7 @@ __global__ __launch_bounds__(WG) void k4_mid(double* cdf, const double* __restri
 // one-GPU fill stage does: the next pf_measure then needs no key pass of its own.
 __global__ __launch_bounds__(NB) void k_apply_pose(const int32_t* __restrict__ slot_anc, int P,
                                                    int offset, double* pose,
-                                                   const double* __restrict__ gathered,
+                                                   const double* __restrict__ gathered, int copy_all,
                                                    int32_t* order_hist, int32_t* order_keys,
                                                    PfOrderParams op) {
     __shared__ int lh[4096];
@@ -897,7 +897,9 @@ __global__ __launch_bounds__(NB) void k_apply_pose(const int32_t* __restrict__ s
         const int a = slot_anc[g];
         const double* src = pose;                           // rows of the ancestor: [9][P] block
         int ai = i;
-        if (a != g) {
+        // copy_all: this rank's own rows are not in `pose` yet either (pf_predict_device left them
+        // in the caller's block, which went into the all-gather): every slot reads the gathered blocks
+        if (a != g || copy_all) {
             if (gathered) {
                 const int r = a / P;
                 ai = a - r * P;
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(NB) void k_apply_pose(const int32_t* __restrict__ s
             order_keys[i] = key;
             atomicAdd(&lh[key], 1);
         }
-        if (a != g) {
+        if (a != g || copy_all) {
 #pragma unroll
             for (int k = 0; k < PF_POSE_ROWS; ++k) pose[(size_t)k * P + i] = src[(size_t)k * P + ai];
         }
@@ -968,12 +970,13 @@ bool pfk_weights_carries(int Pg, bool exact, const int32_t* bmin) {
 hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, float* logw,
                        double* cdf, double* scratch, bool exact, int32_t* first,
                        unsigned long long* counters, PfResampleScratch sc, const int32_t* bmin,
-                       const PfUpdateWork* carry) {
+                       const PfUpdateWork* carry, int n_bmin) {
+    if (n_bmin <= 0) n_bmin = (Pg + 63) / 64;
     if (carry && pfk_weights_carries(Pg, exact, bmin)) {
         const int nb = nblocks(Pg);
         if (bmin) {
             hipLaunchKernelGGL(k3_raw_m_u, dim3(nb + (carry->M + NB - 1) / NB), dim3(NB), 0, st, scores, Pg, w,
-                               scratch, bmin, (Pg + 63) / 64, sc.bsum, sc.bmax, sc.bse, nb, *carry);
+                               scratch, bmin, n_bmin, sc.bsum, sc.bmax, sc.bse, nb, *carry);
         } else {
             hipLaunchKernelGGL(k3_min, dim3(1), dim3(WG), 0, st, scores, Pg, sc.prm);
             hipLaunchKernelGGL(k3_raw_u, dim3(nb + (carry->M + NB - 1) / NB), dim3(NB), 0, st, scores, Pg, w,
@@ -995,7 +998,7 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
         return hipGetLastError();
     }
     if (bmin && !chain_only()) {
-        hipLaunchKernelGGL(k3_raw_m, dim3(nb), dim3(NB), 0, st, scores, Pg, w, scratch, bmin, (Pg + 63) / 64, sc.bsum,
+        hipLaunchKernelGGL(k3_raw_m, dim3(nb), dim3(NB), 0, st, scores, Pg, w, scratch, bmin, n_bmin, sc.bsum,
                            sc.bmax, sc.bse);
     } else {
         hipLaunchKernelGGL(k3_min, dim3(1), dim3(WG), 0, st, scores, Pg, sc.prm);
@@ -1064,7 +1067,7 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
         hipLaunchKernelGGL(k4_apply<false>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
                            pose, pose, bv, bi, nullptr, nullptr, op, counters, hdr);
         hipLaunchKernelGGL(k_apply_pose, dim3(nblocks(P)), dim3(NB), 0, st, slot_anc, P, offset, pose,
-                           pose_gathered, order_hist, order_keys, op);
+                           pose_gathered, (pose_gathered && pose_src != pose) ? 1 : 0, order_hist, order_keys, op);
     }
     if (maps && map_stride) {
         unsigned long long n16 = (map_bytes + 15) / 16;

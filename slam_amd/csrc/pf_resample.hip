@@ -877,24 +877,23 @@ __global__ __launch_bounds__(WG) void k4_mid(double* cdf, const double* __restri
     d4_argmax(nb, sc.bbest_v, sc.bbest_i, best, tile, (int*)(tile + WG), counters, host_out);
 }
 
-// The local shard's pose rows after the resample, and (order_hist != null: 4096-bucket keys) the
-// count of K1's lane-order keys of those poses through a workgroup-private histogram, as the
-// one-GPU fill stage does: the next pf_measure then needs no key pass of its own.
-__global__ __launch_bounds__(NB) void k_apply_pose(const int32_t* __restrict__ slot_anc, int P,
-                                                   int offset, double* pose,
-                                                   const double* __restrict__ gathered, int copy_all,
-                                                   int32_t* order_hist, int32_t* order_keys,
-                                                   PfOrderParams op) {
-    __shared__ int lh[4096];
+// (vb: the 256-particle block of the shard; lh: 4096 ints of LDS; dup_anc: a slot the fill stage has
+// not resolved yet still holds -1 - rank, which names dup_anc[rank])
+__device__ __forceinline__ void d_apply_pose(int vb, int* lh, const int32_t* __restrict__ slot_anc,
+                                             const int32_t* __restrict__ dup_anc, int P, int offset,
+                                             double* pose, const double* __restrict__ gathered,
+                                             int copy_all, int32_t* order_hist, int32_t* order_keys,
+                                             PfOrderParams op) {
     if (order_hist) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) lh[threadIdx.x + NB * k] = 0;
         __syncthreads();
     }
-    const int i = blockIdx.x * NB + threadIdx.x;
+    const int i = vb * NB + threadIdx.x;
     if (i < P) {
         const int g = offset + i;
-        const int a = slot_anc[g];
+        int a = __hip_atomic_load(&slot_anc[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a < 0) a = dup_anc[-1 - a];
         const double* src = pose;                           // rows of the ancestor: [9][P] block
         int ai = i;
         // copy_all: this rank's own rows are not in `pose` yet either (pf_predict_device left them
@@ -926,6 +925,35 @@ __global__ __launch_bounds__(NB) void k_apply_pose(const int32_t* __restrict__ s
             if (c) atomicAdd(&order_hist[b], c);
         }
     }
+}
+// The fill stage of a shard in one launch: workgroups 0 .. nb-1 permute the weights of ALL slots and
+// find their blocks' bests (d4_apply<false>, redundantly on every rank), workgroups nb .. write the
+// local shard's pose rows from the gathered blocks and (order_hist != null: 4096-bucket keys)
+// count K1's lane-order keys of those poses, as the one-GPU fill stage does. The two parts share
+// only slot_anc[], which the second reads whether or not the first has resolved an entry yet.
+__global__ __launch_bounds__(NB) void k4_apply_shard(int32_t* slot_anc, const int32_t* __restrict__ dup_anc,
+                                                     int Pg, double* w, float* logw, double* bbest_v,
+                                                     int32_t* bbest_i, const unsigned long long* counters,
+                                                     unsigned long long* host_hdr, int nb, int P,
+                                                     int offset, double* pose,
+                                                     const double* __restrict__ gathered, int copy_all,
+                                                     int32_t* order_hist, int32_t* order_keys,
+                                                     PfOrderParams op) {
+    __shared__ double sv[NB / WAVE];
+    __shared__ int si[NB / WAVE];
+    __shared__ int lh[4096];
+    if ((int)blockIdx.x >= nb) {
+        d_apply_pose((int)blockIdx.x - nb, lh, slot_anc, dup_anc, P, offset, pose, gathered, copy_all, order_hist,
+                     order_keys, op);
+        return;
+    }
+    if (host_hdr && blockIdx.x == 0 && threadIdx.x == 0) {
+        host_hdr[0] = ld_agent(&counters[0]); host_hdr[1] = ld_agent(&counters[1]);
+        host_hdr[2] = ld_agent(&counters[2]);
+        host_hdr[3] = PF_RESULT_BLOCKS | (unsigned long long)nb;
+    }
+    d4_apply<false>(blockIdx.x, threadIdx.x, sv, si, slot_anc, dup_anc, Pg, w, logw, nullptr, nullptr, bbest_v,
+                    bbest_i, nullptr, nullptr, op, nullptr);
 }
 // Per-particle map slabs (S3P:810 copies the 7.2 MB map with the struct): 16 B per lane.
 __global__ __launch_bounds__(NB) void k_apply_maps(const int32_t* __restrict__ slot_anc, int P,
@@ -1064,10 +1092,9 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
         hipLaunchKernelGGL(k4_apply<true>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
                            pose, pose_src, bv, bi, order_hist, order_keys, op, counters, hdr);
     } else {
-        hipLaunchKernelGGL(k4_apply<false>, dim3(nb), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
-                           pose, pose, bv, bi, nullptr, nullptr, op, counters, hdr);
-        hipLaunchKernelGGL(k_apply_pose, dim3(nblocks(P)), dim3(NB), 0, st, slot_anc, P, offset, pose,
-                           pose_gathered, (pose_gathered && pose_src != pose) ? 1 : 0, order_hist, order_keys, op);
+        hipLaunchKernelGGL(k4_apply_shard, dim3(nb + nblocks(P)), dim3(NB), 0, st, slot_anc, dup_anc, Pg, w, logw,
+                           bv, bi, counters, hdr, nb, P, offset, pose, pose_gathered,
+                           (pose_gathered && pose_src != pose) ? 1 : 0, order_hist, order_keys, op);
     }
     if (maps && map_stride) {
         unsigned long long n16 = (map_bytes + 15) / 16;

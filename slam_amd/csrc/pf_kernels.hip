@@ -384,40 +384,22 @@ __device__ __forceinline__ void col_trip(const PfColG* __restrict__ cg, int g, c
         cnt += T * N;
         return;
     }
-    // some lane is near a rounding boundary or off an axis: column by column. A column that is
-    // fine by itself takes its plain gathers; for the other the reference's fp64 x and y
-    // (S3P:745-747, 880) are computed once, z per beam, and the flat index (S3P:85, 882) is
-    // turned back into the cell it names with integer divisions only when some lane's
-    // coordinates are off an axis while its flat index is in range (the aliasing case).
+    // some lane is near a rounding boundary or off an axis: beam by beam
 #pragma unroll
     for (int q = 0; q < T; ++q) {
-        const unsigned zm = N > 1 ? max((unsigned)Z[q][0], (unsigned)Z[q][N - 1]) : (unsigned)Z[q][0];
-        const bool col_fine = (__builtin_fminf(fx[q], fy[q]) >= L.E) & (__builtin_fmaxf(fx[q], fy[q]) <= L.hi) &
-                              ((unsigned)X[q] < G.gx) & ((unsigned)Y[q] < G.gy) & (zm < G.gz);
-        if (__all(col_fine)) {
-            const unsigned base = swz_col_base((unsigned)X[q], (unsigned)Y[q], G.a, G.b);
-            unsigned v[N];
-#pragma unroll
-            for (int k = 0; k < N; ++k) v[k] = shadow[swz_col_addr(base, (unsigned)Z[q][k], G.b)];
-#pragma unroll
-            for (int k = 0; k < N; ++k) sum += (int)v[k];
-            cnt += N;
-            continue;
-        }
         const double dlx = (double)col[q].lx, dly = (double)col[q].ly;   // exact: integers below 2^24
-        const double Xd = round((L.c * dlx + L.ms * dly) + L.tx);
-        const double Yd = round((L.s * dlx + L.c * dly) + L.ty);
-        const bool xy_in = (Xd >= 0.0) & (Xd < (double)G.gx) & (Yd >= 0.0) & (Yd < (double)G.gy);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            const double Zd = round((double)col[q].lz[k] + L.tz);
-            const double fd = fma(Xd, gp.gyz, fma(Yd, gp.gzd, Zd));
-            const bool ok = (fd >= 0.0) & (fd < gp.elements);          // S3P:882
-            const bool inax = xy_in & (Zd >= 0.0) & (Zd < (double)G.gz);
-            unsigned xc, yc, zc;
-            if (__all(inax | !ok)) {
-                xc = (unsigned)(int)Xd; yc = (unsigned)(int)Yd; zc = (unsigned)(int)Zd;
-            } else {
+            unsigned xc = (unsigned)X[q], yc = (unsigned)Y[q], zc = (unsigned)Z[q][k];
+            bool ok = (xc < G.gx) & (yc < G.gy) & (zc < G.gz);
+            const bool good = (__builtin_fminf(fx[q], fy[q]) >= L.E) & (__builtin_fmaxf(fx[q], fy[q]) <= L.hi) & ok;
+            if (__any(!good)) {
+                // reference sequence S3P:745-747, 880, 85, then the cell the flat index names
+                const double Xd = round((L.c * dlx + L.ms * dly) + L.tx);
+                const double Yd = round((L.s * dlx + L.c * dly) + L.ty);
+                const double Zd = round((double)col[q].lz[k] + L.tz);
+                const double fd = fma(Xd, gp.gyz, fma(Yd, gp.gzd, Zd));
+                ok = (fd >= 0.0) & (fd < gp.elements);                 // S3P:882
                 const unsigned f = ok ? (unsigned)fd : 0u;
                 xc = f / (G.gy * G.gz);
                 const unsigned r = f - xc * (G.gy * G.gz);
@@ -448,9 +430,11 @@ __device__ __forceinline__ void col_phase(const PfColG* __restrict__ cg, int g0,
 }
 
 // ends = {end of the 4-beam groups, of the 3-, of the 2-, of the 1-beam groups} in cg[]
-// (waves_per_eu 8: the launch is sized as one residency of eight 256-thread blocks per CU; at 65
-// VGPRs the eighth does not fit and a second round doubles the tail: 36.4 against 29.8 us. The
-// few values spilled belong to the fp64 branch.)
+// (waves_per_eu 8: the launch is sized as one residency of eight 256-thread blocks per CU, so the
+// register budget is 64 whatever the code does; stated to the compiler it also schedules the
+// loop tighter: 29.8 against 30.5 us at configs[1], 1.16 against 1.30 ms at configs[4]'s share.
+// Measured against it: fp64 x/y once per column and integer divisions only for the aliasing
+// case in the slow branch, 1.45 ms at configs[4]'s share, where a fifth of the trips take it.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_measure_col(
         const double* __restrict__ sorted, int P, const uint8_t* __restrict__ shadow, PfSwz sw,
         const PfColG* __restrict__ cg, int4 ends, PfGridParams gp,

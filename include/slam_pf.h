@@ -251,6 +251,14 @@ int pf_depth_to_cloud(pf_handle* h, const uint8_t* image, int32_t width, int32_t
 int pf_read_occupied(pf_handle* h, int32_t particle, int32_t threshold, int32_t stride, float* xyz_out,
                      int64_t capacity, int64_t* n_out, int64_t* total_out);
 
+/* ---- the resampler's CDF on its own: S3P:763-767 ------------------------------------------------
+ * cdf_out[0] = 0, cdf_out[i+1] = cdf_out[i] + w[i] in index order, fp64, for any host vector w[n]
+ * (cdf_out: host double [n+1]). how = 0: one lane adds in order, the loop as the reference wrote it;
+ * how = 1: the workgroup-wide form pf_resample uses to settle draws on CDF boundaries at particle
+ * counts where the chain would cost milliseconds. Both return the same bits for every input (zeros,
+ * ties, negative and non-finite weights included); exported so that this can be checked directly. */
+int pf_sequential_cdf(pf_handle* h, const double* w, int64_t n, int32_t how, double* cdf_out);
+
 /* ---- multi-GPU: the exchange step inside the library ----------------------------
  * No counterpart in the reference (it is one process on one CPU thread, S3P:1107). One process per
  * GPU, one sharded handle per process. Rank 0 calls pf_comm_unique_id (128 bytes) and hands the id

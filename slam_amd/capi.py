@@ -28,7 +28,7 @@ SYMBOLS = (
     "pfh_snapshot_beams pfh_predict pfh_draw_noise pfh_draw_uniform pfh_add_points_policy "
     "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init "
     "pf_ring_default_params pf_ring_init pf_ring_paint pf_ring_update pf_ring_state "
-    "pf_depth_to_cloud pf_read_occupied pfh_draw_indices pfh_vote_epilogue pfh_pose_message pfh_migration_plan").split()
+    "pf_depth_to_cloud pf_read_occupied pf_sequential_cdf pfh_draw_indices pfh_vote_epilogue pfh_pose_message pfh_migration_plan").split()
 
 
 class Config(C.Structure):
@@ -335,6 +335,14 @@ class Handle:
         self._ck(lib().pf_read_occupied(self._h, C.c_int32(particle), C.c_int32(threshold), C.c_int32(stride),
                                         _p(out), C.c_int64(cap), C.byref(n), C.byref(total)), "pf_read_occupied")
         return out[:n.value].copy(), total.value
+
+    def sequential_cdf(self, w, how=1):
+        """S3P:763-767 on any weight vector: float64 [n+1]. how=0 one-lane chain, how=1 workgroup scan."""
+        w = _c(w, np.float64).reshape(-1)
+        out = np.empty(w.size + 1, np.float64)
+        self._ck(lib().pf_sequential_cdf(self._h, _p(w), C.c_int64(w.size), C.c_int32(how), _p(out)),
+                 "pf_sequential_cdf")
+        return out
 
     def write_local_map(self, src):
         src = _c(src, np.int8).reshape(-1)

@@ -189,7 +189,7 @@ PfGridParams grid_params(const pf_handle* h) {
 hipError_t drop_counted_keys(pf_handle* h) {
     if (!h->hist_counted) return hipSuccess;
     h->hist_counted = false;
-    return hipMemsetAsync(h->order_hist[0], 0, sizeof(int32_t) * 4096, h->stream);
+    return hipMemsetAsync(h->order_hist[0], 0, sizeof(int32_t) * 4096, h->stream);   // only the 12-bit keys are counted ahead
 }
 
 // RCCL is bound at run time (dlopen), so the library loads on hosts without it and a one-GPU
@@ -426,7 +426,6 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->beams_col, (size_t)c.max_beams + 1));
     if (const char* e = getenv("SLAM_PF_TWO_GATHERS")) h->group_gathers = atoi(e) == 0;
     if (const char* e = getenv("SLAM_PF_CHUNKS")) h->tune_chunks = atoi(e);
-    if (h->tune_chunks > h->max_chunks) h->max_chunks = h->tune_chunks < 1024 ? h->tune_chunks : 1024;
     if (h->tune_chunks > h->max_chunks) h->max_chunks = h->tune_chunks < 1024 ? h->tune_chunks : 1024;
     if (const char* e = getenv("SLAM_PF_EXACT_MEASURE")) h->force_exact_measure = atoi(e);
     CREATE_TRY(dalloc(&h->partial, (size_t)h->max_chunks * P));
@@ -884,9 +883,13 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
     const int slot = (int)(h->rs_issued & 1ull);
     {
         Timed t(h, PF_K_RESAMPLE);
-        // FAST order: the parallel sum/scan differs from the sequential one by at most a few
-        // Pg*2^-53 per boundary (all partial sums <= ~1); 8x that as the band.
-        const double bound = h->exact ? 0.0 : 8.0 * (double)h->Pg * 1.1102230246251565e-16;
+        // FAST order: boundary k of the parallel CDF is one fixed tree of at most ~50 roundings on
+        // the raw weights, the sequential one k roundings on the normalised weights plus one per
+        // weight from the division, all of partial sums <= cdf[k]: the two differ by at most
+        // (k + 52) * 2^-53 * cdf[k] * (1 + 1e-9). k_search takes that with 12 % to spare as the band
+        // of boundary k (`bound` = the unit roundoff with the factor); it decides how often a step
+        // pays for the sequential-order CDF: about once per 1/(8e-17 Pg^3) steps.
+        const double bound = h->exact ? 0.0 : 1.125 * 1.1102230246251565e-16;
         // one GPU, shared-key ordering: the fill stage leaves K1's order keys of the new poses
         const PfOrderParams op = order_params(h);
         // (sharded: the kernel that writes the local shard's rows counts them)
@@ -1134,6 +1137,22 @@ static int grow_scratch(pf_handle* h, size_t need) {
     return PF_OK;
 }
 static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+int pf_sequential_cdf(pf_handle* h, const double* w, int64_t n, int32_t how, double* cdf_out) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, w && cdf_out && n >= 1 && n <= (int64_t)1 << 30, "null argument / n outside 1..2^30");
+    NEED(h, how == 0 || how == 1, "how");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t nb_w = sizeof(double) * (size_t)n, nb_c = sizeof(double) * ((size_t)n + 1);
+    if (int rc = grow_scratch(h, up256(nb_w) + nb_c)) return rc;
+    double* d_w = (double*)h->vote_scratch;
+    double* d_c = (double*)(h->vote_scratch + up256(nb_w));
+    HIP_TRY(h, hipMemcpyAsync(d_w, w, nb_w, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, pfk_cdf_of(h->stream, d_w, (int)n, d_c, how));
+    HIP_TRY(h, hipMemcpyAsync(cdf_out, d_c, nb_c, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
 
 int pf_depth_to_cloud(pf_handle* h, const uint8_t* image, int32_t width, int32_t height, int32_t pool,
                       double focal, double* cloud_out, int64_t capacity, int64_t* n_out) {

@@ -157,6 +157,9 @@ static inline size_t pfk_result_slot_bytes(int Pg) {
 }
 // S3P:814-820 from a finished result slot (host memory): first strict maximum above 0, else prev.
 int32_t pfk_result_best(const unsigned long long* slot, int32_t prev);
+// cdf[0] = 0, cdf[i+1] = cdf[i] + w[i] in index order (S3P:763-767), one workgroup: how = 0 the
+// one-lane chain, how = 1 the workgroup scan that gives the same bits (k_cdf_exact_if's form)
+hipError_t pfk_cdf_of(hipStream_t st, const double* w, int n, double* cdf, int how);
 
 // K5: S3P:628-704. rot9: row-major ZYX matrix from the host libm. wpts: double [M][3] scratch.
 struct PfUpdateParams {

@@ -23,6 +23,7 @@
 #define NB 256                   // threads per block of the multi-block kernels
 #define NEVER_DRAWN 0x7f7f7f7f   // "nobody drew this slot": larger than any slot number
 #define PF_MID_MAX 16384         // limit of the one-workgroup forms k3_mid / k4_mid
+#define PF_FOLD_CDF_MAX 32768     // up to here k_first_c rebuilds an ambiguous step's CDF itself
 
 // prm[] layout (device doubles)
 #define PRM_K99 0      // 0.99 * smallest sum (S3P:928)
@@ -213,12 +214,233 @@ __global__ __launch_bounds__(WG) void k_weights_exact(const int2* __restrict__ s
     seq_cdf(w, Pg, cdf, tile);                            // S3P:763-767
 }
 
+// The same prefix sums (S3P:763-767), every value bit-identical to the one-lane chain above, but
+// computed by the whole workgroup. While the running sum s stays inside one binade
+// [2^e, 2^(e+1)), fl(s + w) for 0 <= w < 2^(e+1) is s plus w rounded to a multiple of
+// q = ulp(s) = 2^(e-52); round-to-nearest-even looks at the parity of S = s/q only on an exact
+// tie. The chain of adds is therefore an integer prefix sum whose increments depend on one bit of
+// the running state: an element is the pair (increment when S is even, increment when S is odd),
+// pairs compose associatively, and the workgroup scans XE elements per thread and round. A round
+// ends at the first element that takes the sum out of the binade or is not of that form
+// (negative, NaN, too large); the lane that holds it does that add in hardware and the next round
+// starts behind it. A zero sum is the same scan with every non-zero element ending the round;
+// the first XCHAIN elements, and sums that are negative, not finite or below 2^-960, go by the
+// chain through LDS, XCHAIN elements at a time.
+#define XE 8
+#define XCHAIN 1024               // the first elements (a binade every few of them) go by the chain
+#define XLIM 9007199254740992.0   // 2^53: S/q beyond it means the sum left the binade
+// Integers below 2^53 kept in doubles: adds and compares are single instructions and exact.
+struct IncPair { double e, o; };
+__device__ __forceinline__ bool x_odd(double v) { const double h = v * 0.5; return h != floor(h); }
+__device__ __forceinline__ IncPair inc_then(IncPair a, IncPair b) {  // a's elements first, then b's
+    IncPair r;
+    r.e = a.e + (x_odd(a.e) ? b.o : b.e);
+    r.o = a.o + (x_odd(a.o) ? b.e : b.o);
+    return r;
+}
+__device__ __forceinline__ bool inc_of(double w, double scale, bool zero_sum, IncPair& p) {
+    p.e = p.o = 0.0;
+    if (zero_sum) return w == 0.0;
+    const double x = w * scale;                                      // w / q, exact where it matters
+    if (!(w >= 0.0) || !(x < XLIM)) return false;
+    const double W = floor(x), f = x - W;
+    p.e = p.o = f > 0.5 ? W + 1.0 : W;
+    if (f == 0.5) {                                                  // tie: to the even neighbour
+        const bool odd = x_odd(W);
+        p.e = odd ? W + 1.0 : W;
+        p.o = odd ? W : W + 1.0;
+    }
+    return true;
+}
+__device__ __forceinline__ IncPair shfl_up_pair(IncPair v, int o) {
+    IncPair t;
+    t.e = __shfl_up(v.e, o, WAVE); t.o = __shfl_up(v.o, o, WAVE);
+    return t;
+}
+// One round of the scan in its general form: elements as (even, odd) increment pairs.
+// Called by the whole workgroup after a barrier; ends with the round's results in cdf / s_sh /
+// pos_sh (not yet behind a barrier).
+__device__ __forceinline__ void x_round_pairs(const double (&wk)[XE], double scale, bool zero_sum, double S0,
+                                              double q, int base, int end, double* cdf, IncPair* wtot,
+                                              double* s_sh, int* pos_sh, int* lim_sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    IncPair el[XE];
+    bool ok[XE];
+    IncPair loc{0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < XE; ++k) {
+        el[k].e = el[k].o = 0.0; ok[k] = true;
+        if (base + k < end) ok[k] = inc_of(wk[k], scale, zero_sum, el[k]);
+        loc = inc_then(loc, el[k]);
+    }
+    IncPair inc = loc;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const IncPair t = shfl_up_pair(inc, o);
+        if (lane >= o) inc = inc_then(t, inc);
+    }
+    const IncPair prev = shfl_up_pair(inc, 1);
+    if (lane == WAVE - 1) wtot[wv] = inc;
+    __syncthreads();
+    // the 16 wave totals, scanned by every wave for itself
+    IncPair tot{0.0, 0.0};
+    if (lane < WG / WAVE) tot = wtot[lane];
+#pragma unroll
+    for (int o = 1; o < WG / WAVE; o <<= 1) {
+        const IncPair t = shfl_up_pair(tot, o);
+        if (lane >= o) tot = inc_then(t, tot);
+    }
+    IncPair ex{0.0, 0.0};
+    if (wv > 0) { ex.e = __shfl(tot.e, wv - 1, WAVE); ex.o = __shfl(tot.o, wv - 1, WAVE); }
+    if (lane > 0) ex = inc_then(ex, prev);
+    double S = S0 + (x_odd(S0) ? ex.o : ex.e);
+    double val[XE];
+    double r_stop = 0.0;
+    int my_lim = INT_MAX;
+    bool live = true;
+#pragma unroll
+    for (int k = 0; k < XE; ++k) {
+        val[k] = 0.0;
+        if (live && base + k < end) {
+            const double Sn = S + (x_odd(S) ? el[k].o : el[k].e);
+            if (!ok[k] || !(Sn < XLIM)) {
+                // the add that ends the round, in hardware (only the first such in the
+                // workgroup has a valid S; the others are not used)
+                my_lim = base + k; live = false; r_stop = S * q + wk[k];
+            } else { S = Sn; val[k] = S * q; }
+        }
+    }
+    if (my_lim != INT_MAX) atomicMin(lim_sh, my_lim);
+    __syncthreads();
+    const int lim = *lim_sh;                                         // pos <= lim <= end
+#pragma unroll
+    for (int k = 0; k < XE; ++k) {
+        const int idx = base + k;
+        if (idx < lim) {
+            cdf[idx + 1] = val[k];
+            if (idx == end - 1) { *s_sh = val[k]; *pos_sh = end; }    // (then lim == end)
+        }
+    }
+    if (my_lim == lim) { cdf[lim + 1] = r_stop; *s_sh = r_stop; *pos_sh = lim + 1; }
+}
+
+// tile: XCHAIN doubles of LDS. blockDim.x == WG.
+__device__ __forceinline__ void par_seq_cdf(const double* w, int n, double* cdf, double* tile) {
+    __shared__ IncPair wtot[WG / WAVE];
+    __shared__ double wsum[WG / WAVE];
+    __shared__ double s_sh;
+    __shared__ int pos_sh, lim_sh, tie_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { cdf[0] = 0.0; s_sh = 0.0; pos_sh = 0; tie_sh = 0; }
+    __syncthreads();
+    while (true) {
+        const int pos = pos_sh;
+        const double s = s_sh;
+        if (pos >= n) break;
+        const bool zero_sum = s == 0.0;
+        if (pos < XCHAIN || (!zero_sum && !(s >= 0x1p-960 && s < INFINITY))) {   // uniform over the workgroup
+            const int cnt = min(n - pos, XCHAIN);
+            if (tid < cnt) tile[tid] = w[pos + tid];
+            __syncthreads();
+            if (tid == 0) {
+                double r = s;
+                for (int k = 0; k < cnt; ++k) { r += tile[k]; tile[k] = r; }
+                s_sh = r; pos_sh = pos + cnt;
+            }
+            __syncthreads();
+            if (tid < cnt) cdf[pos + 1 + tid] = tile[tid];
+            __syncthreads();
+            continue;
+        }
+        const int sh = zero_sum ? 0 : 52 - ilogb(s);
+        const double scale = ldexp(1.0, sh), q = zero_sum ? 0.0 : ldexp(1.0, -sh);
+        const double S0 = zero_sum ? 0.0 : s * scale;
+        const int end = (int)min((long long)n, (long long)pos + (long long)WG * XE);
+        const int base = pos + tid * XE;
+        const int nin = min(max(end - base, 0), XE);                 // this thread's elements
+        double wk[XE];
+#pragma unroll
+        for (int k = 0; k < XE; ++k) wk[k] = k < nin ? w[base + k] : 0.0;
+        // Without an exact tie among the round's elements every increment is one number, the
+        // same for either parity, and an element that cannot be scanned is an increment of 2^54:
+        // it stops the round like a change of binade does.
+        double d[XE];
+        double loc = 0.0;
+        bool tie = false;
+#pragma unroll
+        for (int k = 0; k < XE; ++k) {
+            const double x = wk[k] * scale, W = floor(x), f = x - W;
+            const bool valid = zero_sum ? wk[k] == 0.0 : (wk[k] >= 0.0 && x < XLIM);
+            double dk = f > 0.5 ? W + 1.0 : W;
+            dk = valid ? dk : 2.0 * XLIM;
+            dk = k < nin ? dk : 0.0;
+            tie = tie || (k < nin && valid && f == 0.5);
+            d[k] = dk; loc += dk;
+        }
+        if (__ballot(tie) != 0ull && lane == 0) tie_sh = 1;
+        const double inc = wave_scan(loc);
+        if (lane == WAVE - 1) wsum[wv] = inc;
+        if (tid == 0) lim_sh = end;
+        __syncthreads();
+        if (tie_sh) {                                                // uniform
+            x_round_pairs(wk, scale, zero_sum, S0, q, base, end, cdf, wtot, &s_sh, &pos_sh, &lim_sh);
+            if (tid == 0) tie_sh = 0;
+            __syncthreads();
+            continue;
+        }
+        double tot = lane < WG / WAVE ? wsum[lane] : 0.0;
+#pragma unroll
+        for (int o = 1; o < WG / WAVE; o <<= 1) {
+            const double t = __shfl_up(tot, o, WAVE);
+            if (lane >= o) tot += t;
+        }
+        const double S_start = S0 + ((wv > 0 ? __shfl(tot, wv - 1, WAVE) : 0.0) + (inc - loc));
+        double val[XE];
+        double S = S_start;
+        int c = 0;                                                   // elements settled by this thread
+#pragma unroll
+        for (int k = 0; k < XE; ++k) {
+            S += d[k];
+            val[k] = S * q;
+            c += (k < nin && S < XLIM) ? 1 : 0;                      // S never decreases: a prefix of the k
+        }
+        const int my_lim = c < nin ? base + c : INT_MAX;
+        if (my_lim != INT_MAX) atomicMin(&lim_sh, my_lim);
+        __syncthreads();
+        const int lim = lim_sh;                                      // pos <= lim <= end
+#pragma unroll
+        for (int k = 0; k < XE; ++k) {
+            const int idx = base + k;
+            if (idx < lim) {
+                cdf[idx + 1] = val[k];
+                if (idx == end - 1) { s_sh = val[k]; pos_sh = end; }   // (then lim == end)
+            }
+        }
+        if (my_lim == lim) {
+            // the add that ends the round, in hardware, by the lane that holds the element
+            double sp = S_start * q, wc = wk[0];
+#pragma unroll
+            for (int k = 1; k < XE; ++k) if (k == c) { sp = val[k - 1]; wc = wk[k]; }
+            const double r = sp + wc;
+            cdf[lim + 1] = r; s_sh = r; pos_sh = lim + 1;
+        }
+        __syncthreads();
+    }
+}
+
 // Sequential-order CDF of the current weights, only when counters[1] (ambiguous draws) != 0.
 __global__ __launch_bounds__(WG) void k_cdf_exact_if(const double* w, int Pg, double* cdf,
                                                      const unsigned long long* counters) {
-    __shared__ double tile[TILE];
+    __shared__ double tile[XCHAIN];
     if (ld_agent(&counters[1]) == 0) return;
-    seq_cdf(w, Pg, cdf, tile);
+    par_seq_cdf(w, Pg, cdf, tile);
+}
+// S3P:763-767 on any weight vector, by the one-lane chain (how = 0) or the workgroup scan (how = 1):
+// what pf_sequential_cdf exposes so that the two can be compared bit for bit.
+__global__ __launch_bounds__(WG) void k_cdf_of(const double* w, int n, double* cdf, int how) {
+    __shared__ double tile[TILE];
+    if (how == 0) seq_cdf(w, n, cdf, tile);
+    else par_seq_cdf(w, n, cdf, tile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -550,7 +772,10 @@ __device__ inline void d_search(int i, const double* cdf, const double* __restri
     if (!hit) atomicAdd(&counters[0], 1ull);
     if (bound > 0.0) {
         bool amb = !hit;
-        if (hit) amb = (ui - cdf[lo - 1] <= bound) || (cdf[lo] - ui <= bound);
+        // |parallel - sequential| at boundary k <= (k + ~50) roundings of sums <= cdf[k]
+        // (pf_api.hip); `bound` is the unit roundoff with its safety factor
+        const double band = hit ? bound * ((double)lo + 64.0 + (double)(Pg >> 16)) * cdf[lo] : 0.0;
+        if (hit) amb = (ui - cdf[lo - 1] <= band) || (cdf[lo] - ui <= band);
         if (amb) atomicAdd(&counters[1], 1ull);
     }
 }
@@ -1067,8 +1292,12 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
     const bool folded = nb <= WG && !chain_only();
     hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, bound, draw, counters);
     // draws that sit within the parallel CDF's rounding error of a boundary are settled on the
-    // sequential-order CDF of the same weights (nothing happens when there are none)
-    if (folded) {
+    // sequential-order CDF of the same weights (nothing happens when there are none). Such a draw
+    // turns up about once in 1/(8e-17 Pg^3) steps: up to PF_FOLD_CDF_MAX particles that is rare
+    // enough for every workgroup of k_first_c to rebuild the CDF by the one-lane chain when it
+    // happens; beyond, it happens every few steps (every step from a few hundred thousand particles
+    // on), and one workgroup rebuilds it with the parallel form in a launch of its own
+    if (folded && Pg <= PF_FOLD_CDF_MAX) {
         hipLaunchKernelGGL(k_first_c, dim3(nb), dim3(NB), 0, st, (double*)cdf, u, draw, Pg, w, first, counters);
     } else {
         if (bound > 0.0)
@@ -1119,4 +1348,9 @@ int32_t pfk_result_best(const unsigned long long* slot, int32_t prev) {
     for (size_t k = 0; k < nb; ++k)                         // blocks ascend in index: ties keep the earlier one
         if (bi[k] >= 0 && (idx < 0 || bv[k] > v)) { v = bv[k]; idx = bi[k]; }
     return idx >= 0 ? idx : prev;                           // S3P:816: nothing above 0 keeps the previous index
+}
+
+hipError_t pfk_cdf_of(hipStream_t st, const double* w, int n, double* cdf, int how) {
+    hipLaunchKernelGGL(k_cdf_of, dim3(1), dim3(WG), 0, st, w, n, cdf, how);
+    return hipGetLastError();
 }

@@ -238,6 +238,86 @@ def test_fast_order_forms_are_bit_identical(monkeypatch):
             assert np.array_equal(x, y)
 
 
+def _bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def test_workgroup_cdf_is_the_sequential_cdf_bit_for_bit():
+    """The CDF that settles boundary draws at large particle counts is computed by a whole
+    workgroup (integer scan inside each binade of the running sum) and must equal the reference's
+    one-add-after-another loop S3P:763-767 in every bit: against numpy's cumsum (sequential fp64
+    adds) and against the device's own one-lane chain, on normalised weights of several sizes and
+    on inputs made of ties, zeros, binade crossings and values the scan hands back to the chain."""
+    rng = np.random.default_rng(11)
+    cases = {}
+    for n in (1, 7, 64, 4097, 80000, 300001):
+        w = rng.random(n) + 1e-3
+        cases[f"normalised_{n}"] = w / w.sum()
+    w = np.full(80000, 1.0 / 80000); cases["flat_80000"] = w
+    # exact ties: multiples of 2^-54 and 2^-55 meet the ulp 2^-53 of sums in [0.5, 1) half-way
+    k = rng.integers(1, 1 << 12, 50000).astype(np.float64)
+    cases["ties"] = np.concatenate([[0.5], k * 2.0 ** -54, k[:5000] * 2.0 ** -55])
+    cases["ties_odd_start"] = np.concatenate([[0.5 + 2.0 ** -53], np.full(30000, 2.0 ** -54)])
+    z = np.zeros(30000); z[20000] = 0.25; z[20001:20100] = rng.random(99) * 1e-3; z[25000] = 0.75
+    cases["leading_zeros_one_hot"] = z
+    cases["all_zero"] = np.zeros(9000)
+    cases["wide_range"] = 10.0 ** rng.uniform(-30, 3, 40000)                 # many binades, unnormalised
+    cases["tiny"] = rng.random(20000) * 1e-300                               # below the scan's range
+    bad = rng.random(20000) / 20000
+    bad[5000] = -0.125; bad[9000] = np.inf; bad[9001] = -np.inf; bad[15000] = np.nan
+    cases["negative_inf_nan"] = bad
+    neg = rng.random(12000) / 12000; neg[100] = -3.0; neg[8000] = 5.0        # sum negative for a while
+    cases["negative_sum"] = neg
+    cases["denormals"] = np.concatenate([[5e-324] * 100, rng.random(5000) * 1e-310, [1.0], [5e-324] * 100])
+    cases["huge_after_small"] = np.concatenate([rng.random(10000) * 1e-5, [1e200], rng.random(10000), [1e308, 1e308]])
+    h = capi.Handle(_shared_cfg(64, (16, 16, 16)))
+    try:
+        for name, w in cases.items():
+            with np.errstate(all="ignore"):
+                ref = np.concatenate([[0.0], np.cumsum(w)])                  # sequential, index order
+            par = h.sequential_cdf(w, how=1)
+            assert np.array_equal(_bits(par), _bits(ref)) or _same_bits_nan(par, ref), name
+            if w.size <= 100000:
+                chain = h.sequential_cdf(w, how=0)
+                assert np.array_equal(_bits(chain), _bits(ref)) or _same_bits_nan(chain, ref), name
+    finally:
+        h.close()
+
+
+def _same_bits_nan(a, b):
+    """Equal bits wherever b is not NaN, NaN where it is (the payload of a NaN is not a result)."""
+    nan = np.isnan(b)
+    return np.array_equal(np.isnan(a), nan) and np.array_equal(_bits(a)[~nan], _bits(b)[~nan])
+
+
+@pytest.mark.parametrize("P", [50000, 300000])
+def test_boundary_draws_at_large_counts_match_the_sequential_loop(P):
+    """FAST order beyond the size where k_first_c rebuilds the CDF itself (50 k: folded launches
+    + k_cdf_exact_if; 300 k: the unfolded chain): thresholds on and next to CDF boundaries, the
+    resampled slots must be the ones the oracle's sequential loop draws on the same weights."""
+    M, dims = 64, (32, 32, 32)
+    sc = synth.scene(dims, P, M, seed=9)
+    rng = np.random.default_rng(P)
+    w0 = rng.random(P) + 1e-3; w0 /= w0.sum()
+    h = capi.Handle(_shared_cfg(P, dims, order_mode=capi.PF_ORDER_FAST))
+    try:
+        h.write_map(0, sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+        h.set_weights(w0); h.set_beams(*sc["beams"]); h.measure(0); h.weights()
+        gw, _ = h.get_weights()
+        cdf = np.cumsum(gw)                                                  # the sequential CDF of the device's weights
+        u = capi.draw_uniform(5, P)
+        u[:2000] = cdf[1000:3000]                                            # on a boundary: no interval matches
+        u[2000:4000] = np.nextafter(cdf[P // 2:P // 2 + 2000], 1.0)          # just above: the next particle
+        u[4000:6000] = np.nextafter(cdf[P - 2500:P - 500], 0.0)              # just below
+        u[6000] = 0.0; u[6001] = 1.0; u[6002] = np.nextafter(1.0, 0.0)
+        d, sa, best, nohit = O.resample(gw.copy(), u, 0)
+        slots, gbest, gnohit, amb = h.resample(u)
+        assert amb > 0
+        assert np.array_equal(slots, sa) and gbest == best and gnohit == nohit
+    finally:
+        h.close()
+
+
 def test_systematic_thresholds_same_kernel():
     """north_star's systematic resampling = the same kernels fed (u0+i)/N."""
     P, M, dims = 3000, 512, (64, 64, 64)

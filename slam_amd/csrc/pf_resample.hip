@@ -228,6 +228,7 @@ __global__ __launch_bounds__(WG) void k_weights_exact(const int2* __restrict__ s
 // chain through LDS, XCHAIN elements at a time.
 #define XE 8
 #define XCHAIN 1024               // the first elements (a binade every few of them) go by the chain
+#define XT (32 * (XE + 1))         // LDS doubles per wave for the transposed stores (padded rows)
 #define XLIM 9007199254740992.0   // 2^53: S/q beyond it means the sum left the binade
 // Integers below 2^53 kept in doubles: adds and compares are single instructions and exact.
 struct IncPair { double e, o; };
@@ -330,6 +331,7 @@ __device__ __forceinline__ void par_seq_cdf(const double* w, int n, double* cdf,
     __shared__ double wsum[WG / WAVE];
     __shared__ double s_sh;
     __shared__ int pos_sh, lim_sh, tie_sh;
+    __shared__ double xpose[(WG / WAVE) * XT];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) { cdf[0] = 0.0; s_sh = 0.0; pos_sh = 0; tie_sh = 0; }
     __syncthreads();
@@ -409,11 +411,27 @@ __device__ __forceinline__ void par_seq_cdf(const double* w, int n, double* cdf,
         __syncthreads();
         const int lim = lim_sh;                                      // pos <= lim <= end
 #pragma unroll
-        for (int k = 0; k < XE; ++k) {
-            const int idx = base + k;
-            if (idx < lim) {
-                cdf[idx + 1] = val[k];
-                if (idx == end - 1) { s_sh = val[k]; pos_sh = end; }   // (then lim == end)
+        for (int k = 0; k < XE; ++k)
+            if (base + k < lim && base + k == end - 1) { s_sh = val[k]; pos_sh = end; }   // (then lim == end)
+        // results out through a wave-private transpose: a lane's XE values are consecutive in
+        // memory, stored directly every store instruction would write 64 separate 8-byte pieces;
+        // this way it writes one 512-byte run. Half a wave at a time (XT doubles of LDS per wave).
+        {
+            double* tw = xpose + wv * XT;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if ((lane >> 5) == half) {
+#pragma unroll
+                    for (int k = 0; k < XE; ++k) tw[(lane & 31) * (XE + 1) + k] = val[k];
+                }
+                // (LDS operations of one wave complete in order: no barrier between the two loops)
+#pragma unroll
+                for (int j = 0; j < XE / 2; ++j) {
+                    const int m = j * WAVE + lane;                   // element of this half
+                    const int idx = pos + wv * (WAVE * XE) + half * (WAVE * XE / 2) + m;
+                    const double v = tw[(m >> 3) * (XE + 1) + (m & 7)];
+                    if (idx < lim) cdf[idx + 1] = v;
+                }
             }
         }
         if (my_lim == lim) {

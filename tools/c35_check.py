@@ -55,8 +55,14 @@ sg, cg = h.get_scores()
 pickp = np.arange(0, P, max(1, P // 24))
 so, co = O.measure(O.ref_grid(*dims), x[pickp], y[pickp], z[pickp], yaw[pickp], grid.reshape(-1), 0, bx, by, bz, bv, 0)
 assert np.array_equal(sg[pickp], so) and np.array_equal(cg[pickp], co), "scores differ from the oracle"
-h.weights()
 u = capi.draw_uniform(4, P)
+# one untimed weights + resample first (the first launch of a kernel loads its code), then the same
+# state again for the step that is timed and checked
+h.profile(False)
+h.weights(); h.resample(u)
+h.predict(x, y, z, yaw); h.set_weights(np.full(P, 1.0 / P)); h.measure(0)
+h.profile(True)
+h.weights()
 t0 = time.time(); slots, best, nohit, amb = h.resample(u); t1 = time.time() - t0
 w = np.full(P, 1.0 / P); O.weights(w, sg, int(cg[-1])); _, sa, ob, onh = O.resample(w, u, 0)
 assert np.array_equal(slots, sa) and best == ob and nohit == onh, "resampling differs from the oracle"

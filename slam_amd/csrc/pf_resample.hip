@@ -396,7 +396,10 @@ __device__ __forceinline__ void par_seq_cdf(const double* w, int n, double* cdf,
             const double t = __shfl_up(tot, o, WAVE);
             if (lane >= o) tot += t;
         }
-        const double S_start = S0 + ((wv > 0 ? __shfl(tot, wv - 1, WAVE) : 0.0) + (inc - loc));
+        // (the lanes before, from their inclusive sum: inc - loc would lose bits when this
+        // thread's own elements hold the 2^54 of a stop)
+        const double before = __shfl_up(inc, 1, WAVE);
+        const double S_start = S0 + ((wv > 0 ? __shfl(tot, wv - 1, WAVE) : 0.0) + (lane > 0 ? before : 0.0));
         double val[XE];
         double S = S_start;
         int c = 0;                                                   // elements settled by this thread

@@ -266,6 +266,13 @@ def test_workgroup_cdf_is_the_sequential_cdf_bit_for_bit():
     bad = rng.random(20000) / 20000
     bad[5000] = -0.125; bad[9000] = np.inf; bad[9001] = -np.inf; bad[15000] = np.nan
     cases["negative_inf_nan"] = bad
+    # an element the scan cannot take, as the LAST of a thread's eight (the first scan round starts
+    # at 1024 behind the chain): the seven before it must not feel it
+    for nm, v in (("stop_last_of_thread_neg", -1e-9), ("stop_last_of_thread_nan", np.nan),
+                  ("stop_last_of_thread_big", 4.0)):
+        a = (rng.random(30000) + 0.5) / 30000
+        a[1024 + 8 * 100 + 7] = v; a[1024 + 8 * 777 + 5] = v
+        cases[nm] = a
     neg = rng.random(12000) / 12000; neg[100] = -3.0; neg[8000] = 5.0        # sum negative for a while
     cases["negative_sum"] = neg
     cases["denormals"] = np.concatenate([[5e-324] * 100, rng.random(5000) * 1e-310, [1.0], [5e-324] * 100])

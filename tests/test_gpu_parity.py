@@ -273,6 +273,15 @@ def test_workgroup_cdf_is_the_sequential_cdf_bit_for_bit():
         a = (rng.random(30000) + 0.5) / 30000
         a[1024 + 8 * 100 + 7] = v; a[1024 + 8 * 777 + 5] = v
         cases[nm] = a
+    # the same in a round without ties, which runs the plain-sum form and not the pair form:
+    # weights that are integers of 2^-57 (the ulp of sums in [2^-5, 2^-4), reached near index 3000,
+    # left near 6000); a first stop at 3500 pins where the next round starts, the second is then
+    # the last of thread 50's eight
+    for nm, v in (("stop_last_of_thread_plain_neg", -3.0 * 2.0 ** -57), ("stop_last_of_thread_plain_nan", np.nan)):
+        a = rng.integers(1 << 40, 1 << 41, 30000).astype(np.float64) * 2.0 ** -57
+        a[3500] = -5.0 * 2.0 ** -57
+        a[3500 + 1 + 8 * 50 + 7] = v
+        cases[nm] = a
     neg = rng.random(12000) / 12000; neg[100] = -3.0; neg[8000] = 5.0        # sum negative for a while
     cases["negative_sum"] = neg
     cases["denormals"] = np.concatenate([[5e-324] * 100, rng.random(5000) * 1e-310, [1.0], [5e-324] * 100])

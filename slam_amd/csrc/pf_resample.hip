@@ -10,7 +10,9 @@
 //         particle count, never on the grid or the GPU, so every rank that runs this redundantly
 //         gets bit-identical results). The sums differ from the sequential ones by rounding
 //         only; k_search counts the draws that fall within that error of a CDF boundary and
-//         the host re-settles them on the sequential-order CDF (k_cdf_exact_if).
+//         they are searched again on the sequential-order CDF, rebuilt only then (inside
+//         k_first_c up to PF_FOLD_CDF_MAX particles; beyond by k_cdf_exact_if, whose workgroup
+//         computes the chain's exact bits in parallel, par_seq_cdf).
 #include "pf_kernels.h"
 #include "pf_device.h"
 #include <limits.h>

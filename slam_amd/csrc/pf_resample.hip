@@ -786,6 +786,56 @@ __device__ inline int search_draw(const double* __restrict__ cdf, double ui, int
     pos = lo;
     return hit ? lo - 1 : i;
 }
+// What follows the bisection for draw i with threshold ui: lo = first j in [1, Pg] with
+// cdf[j] > ui, Pg + 1 when there is none.
+__device__ inline void d_search_tail(int i, double ui, int lo, const double* cdf, int Pg, double bound,
+                                     int32_t* draw, unsigned long long* counters) {
+    const bool hit = lo <= Pg && cdf[lo - 1] < ui;
+    draw[i] = hit ? lo - 1 : i;
+    if (!hit) atomicAdd(&counters[0], 1ull);
+    if (bound > 0.0) {
+        bool amb = !hit;
+        // |parallel - sequential| at boundary k <= (k + ~50) roundings of sums <= cdf[k]
+        // (pf_api.hip); `bound` is the unit roundoff with its safety factor
+        const double band = hit ? bound * ((double)lo + 64.0 + (double)(Pg >> 16)) * cdf[lo] : 0.0;
+        if (hit) amb = (ui - cdf[lo - 1] <= band) || (cdf[lo] - ui <= band);
+        if (amb) atomicAdd(&counters[1], 1ull);
+    }
+}
+// The same search in two levels: the CDF at the end of every 256-particle block staged in LDS
+// (XTOP entries at most), bisected there, then the eight probes inside the block that holds the
+// boundary. Same result as search_draw on a non-decreasing CDF; a draw close enough to an
+// inversion of the parallel CDF (a few ulp) for the order of the probes to matter is inside the
+// ambiguity band and searched again on the sequential-order CDF anyway. The probes that cost a
+// round trip to L2 drop from ~10 of 14 (10 k particles) or 13 of 17 (80 k) to four.
+#define XTOP 4096
+__global__ __launch_bounds__(NB) void k_search_t(const double* __restrict__ cdf,
+                                                 const double* __restrict__ u, int Pg, double bound,
+                                                 int32_t* __restrict__ draw,
+                                                 unsigned long long* counters) {
+    __shared__ double top[XTOP];
+    const int nb = (Pg + NB - 1) / NB;                       // <= XTOP (pfk_resample)
+    const int i = blockIdx.x * NB + threadIdx.x;
+    const double ui = i < Pg ? u[i] : 0.0;
+    for (int j = threadIdx.x; j < nb; j += NB) top[j] = cdf[min((j + 1) * NB, Pg)];
+    __syncthreads();
+    if (i >= Pg) return;
+    int lo = 0, hi = nb;                                    // first block whose last boundary is above ui
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (top[mid] > ui) hi = mid; else lo = mid + 1;
+    }
+    int pos = Pg + 1;
+    if (lo < nb) {
+        int a = lo * NB + 1, b = min((lo + 1) * NB, Pg);    // cdf[b] > ui
+        while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (cdf[mid] > ui) b = mid; else a = mid + 1;
+        }
+        pos = a;
+    }
+    d_search_tail(i, ui, pos, cdf, Pg, bound, draw, counters);
+}
 __device__ inline void d_search(int i, const double* cdf, const double* __restrict__ u, int Pg,
                                 double bound, int32_t* draw, unsigned long long* counters) {
     if (i >= Pg) return;
@@ -1313,7 +1363,10 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
         return hipGetLastError();
     }
     const bool folded = nb <= WG && !chain_only();
-    hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, bound, draw, counters);
+    if (nb <= XTOP && !chain_only())
+        hipLaunchKernelGGL(k_search_t, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, bound, draw, counters);
+    else
+        hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, bound, draw, counters);
     // draws that sit within the parallel CDF's rounding error of a boundary are settled on the
     // sequential-order CDF of the same weights (nothing happens when there are none). Such a draw
     // turns up about once in 1/(8e-17 Pg^3) steps: up to PF_FOLD_CDF_MAX particles that is rare

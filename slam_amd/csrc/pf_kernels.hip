@@ -696,6 +696,14 @@ __global__ __launch_bounds__(256) void k_order_scatter_s(const int32_t* __restri
     __shared__ int off[4096], lc[4096];
     __shared__ int tot[4];
     const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6;
+    // everything this thread reads from memory first, so that the round trips overlap (loads do
+    // not move up across the barriers below by themselves): its key, its five pose values, its
+    // sixteen counts
+    const int i = blockIdx.x * 256 + lt;
+    const int key = i < P ? keys[i] : 0;
+    double row[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) row[k] = i < P ? pose[(size_t)(4 + k) * P + i] : 0.0;
     int4 v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = ((const int4*)hist)[lt * 4 + k];
@@ -709,6 +717,8 @@ __global__ __launch_bounds__(256) void k_order_scatter_s(const int32_t* __restri
         if (lane >= o) inc += t;
     }
     if (lane == 63) tot[wv] = inc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lc[lt + 256 * k] = 0;
     __syncthreads();
     int run = inc - sum;
     for (int k = 0; k < wv; ++k) run += tot[k];
@@ -725,13 +735,8 @@ __global__ __launch_bounds__(256) void k_order_scatter_s(const int32_t* __restri
     // (LDS), then one global add per key and workgroup for the workgroup's base. Resampled clouds
     // put hundreds of particles into the same few buckets; one returning global atomic each on
     // the same address was most of this kernel's time.
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lc[lt + 256 * k] = 0;
-    __syncthreads();
-    const int i = blockIdx.x * 256 + lt;
-    const int key = i < P ? keys[i] : 0;
     int rank = -1;
-    if (i < P) rank = atomicAdd(&lc[key], 1);
+    if (i < P) rank = atomicAdd(&lc[key], 1);               // (lc was zeroed before the barrier above)
     __syncthreads();
     if (rank == 0) lc[key] = atomicAdd(&cursor[key], lc[key]);   // the only reader and writer of lc[key] here
     __syncthreads();
@@ -739,7 +744,7 @@ __global__ __launch_bounds__(256) void k_order_scatter_s(const int32_t* __restri
     const int r = off[key] + lc[key] + rank;
     order[r] = i;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) sorted[(size_t)k * P + r] = pose[(size_t)(4 + k) * P + i];
+    for (int k = 0; k < 5; ++k) sorted[(size_t)k * P + r] = row[k];
 }
 // hist_counted: hist/keys already hold this pose set's counts and keys (K4's fill stage made
 // them while it wrote the poses). 4096-bucket keys: hist = counts, next_hist = cursor, both left

@@ -92,7 +92,11 @@ __device__ inline void d5_hits(int i, const PfUpdateWork& uw) {
         shadow_touch(up, f, up.hit_inc, up.hit_clamp, true);
 }
 
-// S3P:664-704 for ray r: one wave per ray; lane l takes steps j = 1+l, 65+l, ... (S3P:685: j = 1 .. n_it-1).
+// S3P:664-704 for ray r: PF_RAY_LANES lanes per ray (two rays per wave: a ray of the 3 m range has
+// at most 60 steps, and half as many waves fit the chip in one residency instead of two and a
+// half); lane l takes steps j = 1+l, 1+l+PF_RAY_LANES, ... (S3P:685: j = 1 .. n_it-1).
+#define PF_RAY_LANES 32
+#define PF_RAYS_PER_WG (256 / PF_RAY_LANES)
 __device__ inline void d5_rays(int r, int lane, const PfUpdateWork& uw) {
     const PfUpdateParams& up = uw.up;
     void* grid = uw.grid;
@@ -107,7 +111,7 @@ __device__ inline void d5_rays(int r, int lane, const PfUpdateWork& uw) {
     if (!(rr < 2147483648.0)) return;                            // also drops NaN
     const int n_it = (int)rr;
     const double sx = dx / nc, sy = dy / nc, sz = dz / nc;       // S3P:681-683
-    for (int j = 1 + lane; j < n_it; j += 64) {
+    for (int j = 1 + lane; j < n_it; j += PF_RAY_LANES) {
         const double jd = (double)j;
         const long long f = flat_of((up.pos[0] + sx * jd) * up.conv, (up.pos[1] + sy * jd) * up.conv,
                                     (up.pos[2] + sz * jd) * up.conv, up);   // S3P:687-690

@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256) void k_update_hits(PfUpdateWork uw) {
     d5_hits(blockIdx.x * 256 + threadIdx.x, uw);
 }
 __global__ __launch_bounds__(256) void k_update_rays(PfUpdateWork uw) {
-    d5_rays(blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, uw);
+    d5_rays(blockIdx.x * PF_RAYS_PER_WG + threadIdx.x / PF_RAY_LANES, threadIdx.x % PF_RAY_LANES, uw);
 }
 
 __global__ __launch_bounds__(256) void k_fill_u8(uint4* dst, unsigned long long n16, uint4 v) {
@@ -808,7 +808,7 @@ hipError_t pfk_update_hits(hipStream_t st, const PfUpdateWork& uw) {
 }
 hipError_t pfk_update_rays(hipStream_t st, const PfUpdateWork& uw) {
     if (uw.R == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_update_rays, dim3((uw.R + 3) / 4), dim3(256), 0, st, uw);
+    hipLaunchKernelGGL(k_update_rays, dim3((uw.R + PF_RAYS_PER_WG - 1) / PF_RAYS_PER_WG), dim3(256), 0, st, uw);
     return hipGetLastError();
 }
 hipError_t pfk_fill_u8(hipStream_t st, uint8_t* dst, unsigned long long n, int value) {

@@ -733,14 +733,14 @@ __global__ __launch_bounds__(NB) void k3_norm_c(int Pg, int nb, double* w, const
     d3_norm_c(blockIdx.x, Pg, nb, w, lbuf, logw, bsum, bmax, bse, cdf, first, counters);
 }
 // The same launch carrying the ray phase of the map update (S3P:664-704) in workgroups nb ..,
-// four rays each; the hits rode with the launch before, so they are complete.
+// PF_RAYS_PER_WG rays each; the hits rode with the launch before, so they are complete.
 __global__ __launch_bounds__(NB) void k3_norm_c_u(int Pg, int nb, double* w, const double* lbuf,
                                                   float* __restrict__ logw, const double* bsum,
                                                   const double* bmax, const double* bse, double* cdf,
                                                   int32_t* __restrict__ first,
                                                   unsigned long long* counters, PfUpdateWork uw) {
     if ((int)blockIdx.x >= nb) {
-        d5_rays(((int)blockIdx.x - nb) * 4 + ((int)threadIdx.x >> 6), (int)threadIdx.x & 63, uw);
+        d5_rays(((int)blockIdx.x - nb) * PF_RAYS_PER_WG + (int)threadIdx.x / PF_RAY_LANES, (int)threadIdx.x % PF_RAY_LANES, uw);
         return;
     }
     d3_norm_c(blockIdx.x, Pg, nb, w, lbuf, logw, bsum, bmax, bse, cdf, first, counters);
@@ -1308,7 +1308,7 @@ hipError_t pfk_weights(hipStream_t st, const int2* scores, int Pg, double* w, fl
             hipLaunchKernelGGL(k3_raw_u, dim3(nb + (carry->M + NB - 1) / NB), dim3(NB), 0, st, scores, Pg, w,
                                scratch, sc.prm, sc.bsum, sc.bmax, sc.bse, nb, *carry);
         }
-        hipLaunchKernelGGL(k3_norm_c_u, dim3(nb + (carry->R + 3) / 4), dim3(NB), 0, st, Pg, nb, w, scratch, logw,
+        hipLaunchKernelGGL(k3_norm_c_u, dim3(nb + (carry->R + PF_RAYS_PER_WG - 1) / PF_RAYS_PER_WG), dim3(NB), 0, st, Pg, nb, w, scratch, logw,
                            sc.bsum, sc.bmax, sc.bse, cdf, first, counters, *carry);
         return hipGetLastError();
     }

@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="read every step's results before the next step is enqueued (pf_resample) instead of "
                          "one step later (pf_resample_async / pf_resample_result)")
+    ap.add_argument("--fresh-thresholds", action="store_true",
+                    help="hand pf_resample new thresholds every step (the reference draws them per step, "
+                         "S3P:769) instead of keeping one set resident: 8 B per particle uploaded per step")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal: use the multi-GPU code path (RCCL all-gathers) even at N=1")
     return ap.parse_args()
@@ -180,6 +183,7 @@ def main():
     h.set_beams(*sc["beams"])
     h.set_scan(sc["points"], sc["ray_idx"])
     u = capi.draw_uniform(3, Pg)                     # the same thresholds on every rank
+    u_fresh = [capi.draw_uniform(100 + k, Pg) for k in range(8)] if a.fresh_thresholds else None
     upd = capi.UpdateParams(10, 100, -3, 0, 3.0)
     pos = tp[:3].copy(); zyx = np.array([tp[3], 0.0, 0.0])
     # predicted pose blocks (S3P:911-914 outcome), resident in HBM: NBLK different noise draws
@@ -204,9 +208,12 @@ def main():
         step_no[0] += 1
         be.weights()
 
+    def thresholds():
+        return u_fresh[step_no[0] % 8] if u_fresh else None
+
     def step(first=False):
         enqueue()
-        return be.resample(u if first else None, want_slots=False)
+        return be.resample(u if first else thresholds(), want_slots=False)
 
     def fence():
         h.synchronize()
@@ -232,7 +239,7 @@ def main():
         # reference feeds the filter's correction back asynchronously too, S3P:956-959 / 712-716)
         for i in range(a.steps):
             enqueue()
-            be.resample_async(None, want_slots=False) if sharded else h.resample_async(None, None, False)
+            be.resample_async(thresholds(), want_slots=False) if sharded else h.resample_async(thresholds(), None, False)
             if i:
                 _, _, nohit, amb = be.resample_result()
                 amb_total += amb; nohit_total += nohit
@@ -268,6 +275,7 @@ def main():
                        "particles_per_gpu": P, "particles_total": Pg, "beams": M,
                        "grid": list(dims), "order": "fast" if Pg > 2048 else "exact",
                        "collectives": ("rccl in-library" if getattr(be, "native", False) else "torch.distributed nccl") if sharded else "none",
+                       "thresholds": "new every step, uploaded" if a.fresh_thresholds else "resident",
                        "results_read": "every step, before the next is enqueued" if a.no_pipeline
                                        else "every step, one step late (pf_resample_async)",
                        "ambiguous_draws": int(amb_total), "nohit_draws": int(nohit_total)},

@@ -142,8 +142,9 @@ int pf_weights(pf_handle* h, const void* scores_global_dev);
 /* ---- resample: S3P:757-821 --------------------------------------------------------------- */
 
 /* u_global: n_particles_global thresholds in draw order (reference parity: the mt19937
- * uniforms of S3P:770-773; systematic resampling: (u0+i)/N), or NULL to reuse the resident
- * ones. poses_global_dev: device pointer to the ranks' pose blocks gathered in rank order
+ * uniforms of S3P:770-773; systematic resampling: (u0+i)/N), or NULL to reuse the last set.
+ * The array is copied before the call returns (into pinned memory the search kernel reads: no
+ * device copy is enqueued and the call does not wait for the stream). poses_global_dev: device pointer to the ranks' pose blocks gathered in rank order
  * (each block = what pf_poses_device points to), or NULL on one GPU.
  * slot_anc_out[n_particles_global] (may be NULL) = S3P's resample_index_org; *best_out =
  * S3P's index_high_weight; *nohit_out = draws that matched no interval (kept own index);

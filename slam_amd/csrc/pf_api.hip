@@ -86,6 +86,13 @@ struct pf_handle {
     size_t result_slot_u64 = 0;
     int32_t best_prev = 0;                     // S3P:756: index_high_weight, kept when no weight is above 0
     hipEvent_t rs_event[2] = {nullptr, nullptr};   // recorded behind each slot's resample
+    // The caller's thresholds are staged per result slot in pinned, device-mapped memory and K4's
+    // search reads them from there (8 B per draw over PCIe, once): no copy is enqueued and the call
+    // does not wait for the stream. A copy on the compute stream between two kernels cost 40 us
+    // per step. A later call without thresholds first brings the last set into HBM (u), once.
+    double* h_u = nullptr;                         // pinned [2][Pg]
+    double* d_u_map = nullptr;                     // the same memory as the device sees it
+    int u_src = -1;                                // slot of h_u that holds the current set, -1: `u` does
     unsigned long long rs_issued = 0, rs_done = 0; // resamples enqueued / results handed out
     unsigned long long* counters = nullptr;   // [3]
     PfResampleScratch rs{};            // block-level scratch of K3/K4
@@ -319,6 +326,7 @@ void pf_destroy(pf_handle* h) {
     if (h->poses_all) (void)hipFree(h->poses_all);
     for (hipEvent_t e : h->rs_event) if (e) (void)hipEventDestroy(e);
     if (h->h_result) (void)hipHostFree(h->h_result);
+    if (h->h_u) (void)hipHostFree(h->h_u);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -442,6 +450,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(hipHostMalloc((void**)&h->h_result, 2 * pfk_result_slot_bytes(h->Pg), hipHostMallocMapped));
     memset(h->h_result, 0, 2 * pfk_result_slot_bytes(h->Pg));
     CREATE_TRY(hipHostGetDevicePointer((void**)&h->d_result, h->h_result, 0));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_u, 2 * sizeof(double) * Pg, hipHostMallocMapped));
+    CREATE_TRY(hipHostGetDevicePointer((void**)&h->d_u_map, h->h_u, 0));
     CREATE_TRY(hipEventCreateWithFlags(&h->rs_event[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->rs_event[1], hipEventDisableTiming));
     {
@@ -875,12 +885,21 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
     h->poses_gathered = false;
     if (poses_global_dev && poses_global_dev != (const void*)h->poses_all)
         HIP_TRY(h, materialize_pose(h));              // the caller's gather: kept slots stay where they are in h->pose
-    if (u) {
-        HIP_TRY(h, hipMemcpyAsync(h->u, u, sizeof(double) * (size_t)h->Pg, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        h->have_u = true;
-    }
     const int slot = (int)(h->rs_issued & 1ull);
+    const double* u_dev = h->u;
+    if (u) {
+        // this slot's buffer is free: its previous set belongs to a resample whose results have
+        // been handed out (at most two are outstanding)
+        memcpy(h->h_u + (size_t)slot * (size_t)h->Pg, u, sizeof(double) * (size_t)h->Pg);
+        h->u_src = slot;
+        h->have_u = true;
+        u_dev = h->d_u_map + (size_t)slot * (size_t)h->Pg;
+    } else if (h->u_src >= 0) {
+        HIP_TRY(h, hipMemcpyAsync(h->u, h->h_u + (size_t)h->u_src * (size_t)h->Pg, sizeof(double) * (size_t)h->Pg,
+                                  hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));     // once per switch: the slot may be refilled by the next call
+        h->u_src = -1;
+    }
     {
         Timed t(h, PF_K_RESAMPLE);
         // FAST order: boundary k of the parallel CDF is one fixed tree of at most ~50 roundings on
@@ -894,7 +913,7 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
         const PfOrderParams op = order_params(h);
         // (sharded: the kernel that writes the local shard's rows counts them)
         const bool count_keys = op.mode != 0 && op.bits == 4;
-        HIP_TRY(h, pfk_resample(h->stream, h->cdf, h->u, h->Pg, h->P, h->offset, bound, h->w, h->logw,
+        HIP_TRY(h, pfk_resample(h->stream, h->cdf, u_dev, h->Pg, h->P, h->offset, bound, h->w, h->logw,
                                 h->pose, h->pose_src, (const double*)poses_global_dev, h->slab ? h->maps : nullptr,
                                 h->slab, (unsigned long long)h->elements, h->draw, h->first, h->dup_anc,
                                 h->free_slot, h->slot_anc, h->best, h->counters, h->rs, h->d_result + h->result_slot_u64 * slot,

@@ -1030,6 +1030,9 @@ def test_async_resample_pipeline_equals_the_blocking_calls():
     P, M, dims, steps = 6000, 500, (96, 96, 64), 6
     sc = synth.scene(dims, P, M, seed=61)
     u = capi.draw_uniform(17, P)
+    # thresholds: new ones in three steps running (the pinned staging slots alternate and are reused
+    # while a resample is in flight), then the last set again, a new one, the last set again
+    us = [u, capi.draw_uniform(18, P), capi.draw_uniform(19, P), None, capi.draw_uniform(20, P), None]
     upd = capi.UpdateParams(10, 100, -3, 0, 3.0)
     tp = sc["true_pose"]
     pos = tp[:3].copy(); zyx = np.array([tp[3], 0.0, 0.0])
@@ -1051,9 +1054,9 @@ def test_async_resample_pipeline_equals_the_blocking_calls():
                 h.measure(0); h.update_map(capi.PF_GRID_SHARED, upd, pos, zyx)
                 h.predict_device(blocks[i].data_ptr()); h.weights()
                 if mode == "blocking":
-                    res.append(h.resample(u if i == 0 else None))
+                    res.append(h.resample(us[i]))
                 else:
-                    h.resample_async(u if i == 0 else None, None, True)
+                    h.resample_async(us[i], None, True)
                     if i:
                         res.append(h.resample_result())
             if mode == "async":

@@ -315,6 +315,12 @@ void pfh_draw_indices(uint32_t seed, int64_t n, int32_t hi, int32_t* idx);
 void pfh_vote_epilogue(double pos_scan[3], double* yaw_scan, const double loc[4], double gyr_yaw,
                        double* gyr_yaw_old, double pos_diff_out[3], double* yaw_diff_scan_out,
                        double* yaw_diff_out);
+/* S3P:712-728, update_realtime_pos(): the dead-reckoned global pose advances by the frame's scan
+ * increment (rotated by the current yaw) plus the filter's pending correction feedback[4] =
+ * {pos_xyz_diff[3], rot_z_diff} (S3P:956-959), yaw wrapped to (-pi, pi]; the correction is consumed
+ * (zeroed). pos[3] and *yaw are in/out. */
+void pfh_update_realtime_pos(double pos[3], double* yaw, const double pos_diff_scan[3], double yaw_diff,
+                             double feedback[4]);
 /* S3P:207-222, the pose message convention: position (x, -z, y), orientation (w, x, y, z) =
  * (cos(a), 0, sin(a), 0) with a = (-yaw - pi/2)/2. */
 void pfh_pose_message(const double pos[3], double yaw, double position_out[3],

@@ -10,6 +10,7 @@
 #pragma once
 #include <random>
 #include <cstring>
+#include <vector>
 
 extern "C" unsigned pf_ref_next_seed;          // defined in ref_harness_tail.cpp
 struct pf_fixed_random_device {

@@ -28,7 +28,8 @@ SYMBOLS = (
     "pfh_snapshot_beams pfh_predict pfh_draw_noise pfh_draw_uniform pfh_add_points_policy "
     "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init "
     "pf_ring_default_params pf_ring_init pf_ring_paint pf_ring_update pf_ring_state "
-    "pf_depth_to_cloud pf_read_occupied pf_sequential_cdf pfh_draw_indices pfh_vote_epilogue pfh_pose_message pfh_migration_plan").split()
+    "pf_depth_to_cloud pf_read_occupied pf_sequential_cdf pfh_draw_indices pfh_vote_epilogue pfh_pose_message pfh_migration_plan "
+    "pfh_update_realtime_pos").split()
 
 
 class Config(C.Structure):
@@ -448,6 +449,15 @@ def vote_epilogue(pos_scan, yaw_scan, loc, gyr_yaw, gyr_yaw_old):
     lib().pfh_vote_epilogue(_p(pos), C.byref(yaw), _p(loc), C.c_double(gyr_yaw), C.byref(old), _p(pd),
                             C.byref(ds), C.byref(d))
     return pos, yaw.value, old.value, pd, ds.value, d.value
+
+
+def update_realtime_pos(pos, yaw, pos_diff_scan, yaw_diff, feedback):
+    """S3P:712-728. Returns (pos[3], yaw); `feedback` (float64 [4]) is consumed in place."""
+    pos = np.array(pos, np.float64); pd = _c(pos_diff_scan, np.float64)
+    assert feedback.dtype == np.float64 and feedback.flags.c_contiguous and len(feedback) == 4
+    y = C.c_double(yaw)
+    lib().pfh_update_realtime_pos(_p(pos), C.byref(y), _p(pd), C.c_double(yaw_diff), _p(feedback))
+    return pos, y.value
 
 
 def pose_message(pos, yaw):

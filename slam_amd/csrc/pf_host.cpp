@@ -115,6 +115,19 @@ void pfh_vote_epilogue(double pos_scan[3], double* yaw_scan, const double loc[4]
     *yaw_diff_out = (diff_gyr + diff_scan) / 2;                               // S3P:404
 }
 
+void pfh_update_realtime_pos(double pos[3], double* yaw, const double pos_diff_scan[3], double yaw_diff,
+                             double feedback[4]) {
+    const double pi = 2 * acos(0.0);                                          // S3P:24
+    const double e0 = *yaw;
+    pos[0] += cos(e0) * pos_diff_scan[0] - sin(e0) * pos_diff_scan[1] + feedback[0];   // S3P:713
+    pos[1] += sin(e0) * pos_diff_scan[0] + cos(e0) * pos_diff_scan[1] + feedback[1];   // S3P:714
+    pos[2] += pos_diff_scan[2] + feedback[2];                                 // S3P:715
+    *yaw += yaw_diff + feedback[3];                                           // S3P:716
+    if (*yaw > pi) *yaw += -2 * pi;                                           // S3P:717-722
+    else if (*yaw < -pi) *yaw += 2 * pi;
+    feedback[0] = feedback[1] = feedback[2] = feedback[3] = 0;                // S3P:723-726
+}
+
 void pfh_pose_message(const double pos[3], double yaw, double position_out[3], double orientation_wxyz_out[4]) {
     const double pi = 2 * acos(0.0);
     orientation_wxyz_out[0] = cos((-yaw - pi / 2) / 2);                       // S3P:212-215

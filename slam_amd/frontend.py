@@ -1,0 +1,127 @@
+"""Host-driver mirror of the reference's Slam::callback() (S3P:168-205): what the caller keeps on
+the host per depth frame — the members of class Slam that carry the scan pose, the vote's last
+hypothesis, the IMU angle bookkeeping, the local frame's pose and the dead-reckoned global pose —
+while the loops go to the GPU through the C ABI (include/slam_pf.h) in the reference's order:
+
+    pf_depth_to_cloud                  resize_depth_to_array + img_to_cloud      S3P:173-175, 562-612
+    pf_ring_paint, pf_scan_vote        scan_localization                         S3P:300-376
+    pfh_vote_hypothesis / _epilogue                                              S3P:366-404
+    pf_ring_update                     scan_localization_map_update              S3P:419-529
+    pf_set_scan, pf_update_map         build_local_map                           S3P:621-704
+    pfh_update_realtime_pos            update_realtime_pos                       S3P:712-728
+
+`loc` is a PF_MAP_SHARED handle holding the binary localisation grid (S3P:64) with its keyframe
+ring; `mapper` is the handle whose int8 local map (S3P:65) build_local_map() writes — the filter's
+own handle in the reference's layout. Both are slam_amd.capi.Handle objects (or, in the CPU suite,
+test doubles with the same methods). Nothing here computes a result the reference computes in its
+loops. driver/step_loop.cpp is the same caller in C++.
+"""
+import numpy as np
+
+from . import capi
+
+VOTE = dict(n_yaw=5, yaw_k0=-6, yaw_kstep=3, n_t=5, length=0.25)      # S3P:275-279, 328-348
+N_SCAN_POINTS = 500                                                  # S3P:261
+N_RAYS = 2400                                                        # S3P:668
+
+
+class FrameLoop:
+    def __init__(self, loc, mapper, width=640, height=480, pool=4, focal=385.0 / 4.0, resolution=0.05,
+                 map_size=(10, 10, 4)):
+        self.loc, self.mapper = loc, mapper
+        self.width, self.height, self.pool, self.focal = width, height, pool, focal
+        self.resolution = resolution
+        half = [map_size[0] // 2, map_size[1] // 2, map_size[2] // 2]   # S3P:269-271: integer halves
+        # members of class Slam
+        self.pos_scan = np.array(half, np.float64)                   # S3P:282
+        self.yaw_scan = 0.0                                          # S3P:281
+        self.vote_loc = np.array(half + [0.0], np.float64)           # S3P:265, 269-271: Tx_loc..rot_z_loc
+        self.gyr_zyx = np.zeros(3)                                   # S3P:150
+        self.gyr_yaw_old = 0.0                                       # S3P:141
+        self.yaw_diff_scan = 0.0                                     # S3P:142
+        self.pos_diff_scan = np.zeros(3)                             # S3P:143
+        self.yaw_diff = 0.0                                          # S3P:139
+        self.rot_y, self.rot_x = 0.0, 0.1                            # S3P:267-268
+        # globals S3P:56-61
+        self.local_pos = np.array([map_size[0] / 2, map_size[1] / 2, 1.5])
+        self.local_yaw = 0.0
+        self.pos = np.array([7.5, 7.5, 1.5])
+        self.yaw = 0.0
+        self.feedback = np.zeros(4)                                  # pos_xyz_diff, rot_z_diff
+        self.update_params = capi.UpdateParams(10, 50, -3, -50, 3.0)  # S3P:637, 650-655, 695-700
+        self.n = 0
+        # cloudpoints (S3P:126): rows beyond the current count keep what earlier frames left there
+        self.cloud = np.zeros(((width // pool) * (height // pool) + 1, 3), np.float64)
+        self.last_vote = -1
+        self.last_flags = 0
+
+    # ---- S3P:173-185 ----
+    def depth(self, image):
+        c = self.loc.depth_to_cloud(image, self.width, self.height, self.pool, self.focal)
+        self.n = len(c)
+        self.cloud[:self.n] = c
+        return self.cloud[:self.n]
+
+    def set_gyr(self, zyx=None):
+        """zyx: what sync_filter() would leave (S3P:244-246); None: no IMU sample (S3P:184)."""
+        if zyx is None:
+            self.gyr_zyx[0] = self.yaw + self.yaw_diff_scan
+        else:
+            self.gyr_zyx[:] = zyx
+
+    # ---- scan_localization(): S3P:300-410 ----
+    def scan_localization(self, seed):
+        self.rot_y, self.rot_x = float(self.gyr_zyx[1]), float(self.gyr_zyx[2])      # S3P:301-302
+        self.loc.ring_paint()                                                        # S3P:305-312
+        pick = capi.draw_indices(seed, N_SCAN_POINTS, self.n)                        # S3P:315-319, inclusive
+        sample = self.cloud[pick]                                                    # S3P:320-322
+        zyx = (self.yaw_scan, self.rot_y, self.rot_x)
+        _, best = self.loc.scan_vote(sample, self.pos_scan, zyx, **VOTE)             # S3P:328-376
+        hyp = capi.vote_hypothesis(best, self.pos_scan, zyx, self.resolution, **VOTE)
+        if hyp is not None:                                                          # S3P:365-372
+            self.vote_loc[:] = hyp
+        self.last_vote = best
+        (self.pos_scan, self.yaw_scan, self.gyr_yaw_old, self.pos_diff_scan, self.yaw_diff_scan,
+         self.yaw_diff) = capi.vote_epilogue(self.pos_scan, self.yaw_scan, self.vote_loc,
+                                             float(self.gyr_zyx[0]), self.gyr_yaw_old)   # S3P:379-404
+        return pick
+
+    # ---- scan_localization_map_update(): S3P:419-529 ----
+    def map_update(self):
+        zyx = (self.yaw_scan, self.rot_y, self.rot_x)
+        self.last_flags, self.pos_scan = self.loc.ring_update(self.cloud[:self.n], self.pos_scan, zyx)
+        return self.last_flags
+
+    # ---- build_local_map(): S3P:621-710 (the caller holds its mutex around this, S3P:622/708) ----
+    def build_local_map(self, seed):
+        self.local_pos = self.local_pos + self.pos_diff_scan                         # S3P:623-625
+        self.local_yaw = self.local_yaw + self.yaw_diff                              # S3P:626
+        rays = capi.draw_indices(seed, N_RAYS, self.n)                               # S3P:664-669, inclusive
+        if np.any(rays >= self.n):
+            raise ValueError("a ray index names the row behind the cloud (S3P:666 draws it; the "
+                             "reference then marches to a stale point): draw in [0, n-1]")
+        self.mapper.set_scan(self.cloud[:self.n], rays)
+        self.mapper.update_map(capi.PF_GRID_LOCAL, self.update_params, self.local_pos,
+                               (self.local_yaw, self.rot_y, self.rot_x))             # S3P:628-704
+        self.pos, self.yaw = capi.update_realtime_pos(self.pos, self.yaw, self.pos_diff_scan,
+                                                      self.yaw_diff, self.feedback)  # S3P:706, 712-728
+        return rays
+
+    def frame(self, image, gyr_zyx, seed_vote, seed_rays):
+        """One callback() (S3P:168-205) without the ROS message handling."""
+        self.depth(image)
+        self.set_gyr(gyr_zyx)
+        self.scan_localization(seed_vote)
+        self.map_update()
+        self.build_local_map(seed_rays)
+
+    # ---- the snapshot of particle_map(): S3P:833-846 (under the caller's mutex) ----
+    def snapshot(self, origin=(100, 100, 30)):
+        """Returns (beams, local_pose[4], global_pose[4]) and resets the local map and frame."""
+        cfg = self.mapper.cfg
+        local = self.mapper.read_local_map().reshape(cfg.local_x, cfg.local_y, cfg.local_z)
+        local_pose = np.array([*self.local_pos, self.local_yaw])
+        global_pose = np.array([*self.pos, self.yaw])
+        self.mapper.reset_local_map()                                                # S3P:840
+        self.local_pos = np.array([5.0, 5.0, 1.5]); self.local_yaw = 0.0             # S3P:841-844
+        return capi.snapshot_beams(local, origin), local_pose, global_pose

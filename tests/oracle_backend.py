@@ -107,3 +107,69 @@ class OracleHandle:
         O.permute(sa, lw)
         self.logw = lw
         return sa, best, nohit, 0
+
+
+class _Cfg:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class OracleLocHandle:
+    """Test double of the PF_MAP_SHARED handle that holds the binary localisation grid (S3P:64) and
+    its keyframe ring: the methods slam_amd.frontend.FrameLoop calls, loops = the CPU oracle."""
+
+    def __init__(self, dims=(200, 200, 80), resolution=0.05):
+        self.dims, self.resolution = dims, resolution
+        self.grid = np.zeros(dims, np.uint8)
+        self.ring = O.RingState(dims, resolution)
+
+    def depth_to_cloud(self, image, width, height, pool=4, focal=385.0 / 4.0):
+        return O.depth_to_cloud(image, width, height, pool, focal)
+
+    def ring_paint(self):
+        self.ring.paint(self.grid)
+
+    def scan_vote(self, points, pos, zyx, **kw):
+        return O.scan_vote(self.grid, self.resolution, points, pos, zyx, **kw)
+
+    def ring_update(self, cloud, pos_scan, zyx):
+        return self.ring.update(self.grid, cloud, pos_scan, zyx)
+
+    def ring_state(self, with_idx=False):
+        r = self.ring
+        return (r.count.copy(), r.life.copy(), np.array(r.r.pos_update[:]), np.array(r.r.euler_update[:]),
+                r.idx.reshape(r.r.n_slots, r.r.cap).copy() if with_idx else None)
+
+    def read_map(self, i=0):
+        return self.grid.reshape(-1).copy()
+
+    def write_map(self, i, src):
+        self.grid.reshape(-1)[:] = src
+
+
+class OracleMapper:
+    """Test double of the handle whose int8 local map (S3P:65) build_local_map() writes."""
+
+    def __init__(self, dims=(200, 200, 80), resolution=0.05):
+        self.cfg = _Cfg(local_x=dims[0], local_y=dims[1], local_z=dims[2])
+        self.resolution = resolution
+        self.local = np.zeros(dims[0] * dims[1] * dims[2], np.int8)
+
+    def set_scan(self, points, ray_idx):
+        self.points = np.array(points, np.float64).reshape(-1, 3)
+        self.rays = np.array(ray_idx, np.int32)
+
+    def update_map(self, target, params, pos, zyx):
+        c = self.cfg
+        cfg = O.UpdateCfg(c.local_x, c.local_y, c.local_z, self.resolution, 1, params.hit_inc, params.hit_clamp,
+                          params.miss_inc, params.miss_clamp, params.max_range)
+        O.update_map(cfg, self.local, pos, zyx, self.points, self.rays)
+
+    def write_local_map(self, src):
+        self.local[:] = np.asarray(src, np.int8).reshape(-1)
+
+    def read_local_map(self):
+        return self.local.copy()
+
+    def reset_local_map(self):
+        self.local[:] = 0

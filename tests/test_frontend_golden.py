@@ -1,0 +1,54 @@
+"""CPU suite, per-frame half of the path: the oracle's restatements of the depth front-end, the
+scan vote, the keyframe ring and the local-map update (oracle/pf_oracle.c) and the product's host
+mirror of callback() (slam_amd/frontend.py + the pfh_* helpers) against vectors produced by the
+REFERENCE'S OWN class Slam (tests/golden/{depth,vote,local_map,ring,frames,helpers_p}.npz, generator
+oracle/make_golden_frontend.py). Bar: bit-exact."""
+import numpy as np
+
+from oracle import binding as O
+from oracle_backend import OracleHandle, OracleLocHandle, OracleMapper
+import golden_util as G
+
+
+def test_reverse_index_conv_p_matches_reference(golden_dir):
+    """S3P:100-110 (double arithmetic on the 300 x 300 x 80 grid) == the integer split, and the
+    oracle's read-out uses it: pfo_read_occupied on a grid holding exactly those cells."""
+    g = G.load(golden_dir, "helpers_p.npz")
+    js, rev = g["js_p"].astype(np.int64), g["rev_p"].astype(np.int64)
+    assert np.array_equal(np.stack([js // 24000, (js % 24000) // 80, js % 80], 1), rev)
+    grid = np.zeros((300, 300, 80), np.uint8)
+    grid.reshape(-1)[js] = 81
+    got = O.read_occupied(grid, 0.05, 80, 1)
+    o = np.argsort(js); u = np.concatenate([[True], np.diff(js[o]) != 0])
+    r = rev[o][u]
+    want = np.stack([(r[:, 0] * 0.05), (-r[:, 2] * 0.05), (r[:, 1] * 0.05)], 1).astype(np.float32)
+    assert np.array_equal(got, want)
+
+
+def test_depth_front_end_matches_reference(golden_dir):
+    g = G.load(golden_dir, "depth.npz")
+    cloud = O.depth_to_cloud(g["image"].astype("<u2").tobytes())
+    assert len(cloud) == int(g["n"])
+    assert np.array_equal(cloud, g["cloud_mm"].astype(np.float64) / 1000.0)
+    # the integer millimetre arrays of S3P:565-568, through the cloud (dropped pixels have depth_y 0)
+    keep = g["depth_y"].reshape(-1) != 0
+    mm = np.stack([g["depth_x"].reshape(-1)[keep], g["depth_y"].reshape(-1)[keep], g["depth_z"].reshape(-1)[keep]], 1)
+    assert np.array_equal(cloud, mm / 1000.0)
+
+
+def test_scan_vote_matches_reference(golden_dir):
+    G.check_vote_cases(golden_dir, OracleLocHandle)
+
+
+def test_local_map_update_matches_reference(golden_dir):
+    G.check_local_map_cases(golden_dir, OracleMapper)
+
+
+def test_keyframe_ring_matches_reference(golden_dir):
+    G.check_ring_calls(golden_dir, OracleLocHandle())
+
+
+def test_callback_and_particle_loop_matches_reference(golden_dir):
+    """48 frames of callback() with particle_map() every 8 frames, past a recentring of the
+    localisation grid: the reference's own run in the build container."""
+    G.check_frames(golden_dir, OracleLocHandle(), OracleMapper(), OracleHandle(50))

@@ -1,0 +1,114 @@
+"""GPU parity tests (-m gpu), per-frame half of the path: the HIP kernels behind pf_depth_to_cloud,
+pf_scan_vote, pf_ring_*, pf_update_map and pf_read_occupied, called through the C ABI, against the
+vectors produced by the REFERENCE'S OWN class Slam (tests/golden/{depth,vote,local_map,ring,frames,
+helpers_p}.npz; generator oracle/make_golden_frontend.py). Bar: bit-exact."""
+import numpy as np
+import pytest
+
+from slam_amd import capi
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def loc_handle():
+    """The localisation grid (S3P:64: 200 x 200 x 80 binary uint8) with its keyframe ring."""
+    h = capi.Handle(capi.default_config(n_particles=1, map_mode=capi.PF_MAP_SHARED, grid_x=200, grid_y=200,
+                                        grid_z=80, local_x=0, local_y=0, local_z=0, max_beams=64))
+    h.fill_maps(0)
+    h.ring_init()
+    return h
+
+
+def mapper_handle(P=1):
+    """The filter's handle at the reference's sizes: per-particle 300 x 300 x 80 maps + the int8
+    local map build_local_map() writes (S3P:65)."""
+    return capi.Handle(capi.default_config(n_particles=P, max_beams=1 << 18))
+
+
+def test_depth_front_end_matches_reference(golden_dir):
+    g = G.load(golden_dir, "depth.npz")
+    h = loc_handle()
+    try:
+        cloud = h.depth_to_cloud(g["image"].astype("<u2").tobytes(), 640, 480)
+        assert len(cloud) == int(g["n"])
+        assert np.array_equal(cloud, g["cloud_mm"].astype(np.float64) / 1000.0)
+    finally:
+        h.close()
+
+
+def test_scan_vote_matches_reference(golden_dir):
+    G.check_vote_cases(golden_dir, loc_handle)
+
+
+def test_local_map_update_matches_reference(golden_dir):
+    G.check_local_map_cases(golden_dir, mapper_handle)
+
+
+def test_keyframe_ring_matches_reference(golden_dir):
+    h = loc_handle()
+    try:
+        G.check_ring_calls(golden_dir, h)
+    finally:
+        h.close()
+
+
+def test_read_out_matches_reference_index_split(golden_dir):
+    """pf_read_occupied (S3P:1031-1051) on the reference's 300 x 300 x 80 grid: the cells of
+    helpers_p.npz come back as the triples reverse_index_conv_p (S3P:100-110) gives for them."""
+    g = G.load(golden_dir, "helpers_p.npz")
+    js, rev = g["js_p"].astype(np.int64), g["rev_p"].astype(np.int64)
+    h = mapper_handle()
+    try:
+        grid = np.zeros(300 * 300 * 80, np.uint8)
+        grid[js] = 81
+        h.write_map(0, grid)
+        got, total = h.read_occupied(0, 80, 1)
+        o = np.argsort(js); u = np.concatenate([[True], np.diff(js[o]) != 0])
+        r = rev[o][u]
+        want = np.stack([(r[:, 0] * 0.05), (-r[:, 2] * 0.05), (r[:, 1] * 0.05)], 1).astype(np.float32)
+        assert total == len(want) and np.array_equal(got, want)
+        sel = np.unique(js[js % 4 == 0])
+        got4, total4 = h.read_occupied(0, 80, 4)
+        assert total4 == len(sel)
+    finally:
+        h.close()
+
+
+def test_callback_and_particle_loop_matches_reference(golden_dir):
+    """The reference's own loop (48 callback() frames, particle_map() every 8, one recentring of the
+    localisation grid) through the C ABI: depth image -> cloud -> vote -> ring -> local map ->
+    snapshot -> measure/fuse -> weights -> resample, every member and map equal after every call."""
+    loc, flt = loc_handle(), mapper_handle(50)
+    try:
+        G.check_frames(golden_dir, loc, flt, flt)
+    finally:
+        loc.close(); flt.close()
+
+
+def test_scan_vote_leaves_the_scan_alone(golden_dir):
+    """pf_set_scan -> pf_scan_vote -> pf_update_map on ONE handle: the vote's sampled points must not
+    disturb the scan the update marches over."""
+    from oracle import binding as O
+    g = G.load(golden_dir, "local_map.npz")
+    name = "m0_fresh"
+    cloud = G.cloud_of(g[name + "_cloud_mm"])
+    rays = g[name + "_rays"]
+    dims = (200, 200, 80)
+    h = capi.Handle(capi.default_config(n_particles=1, map_mode=capi.PF_MAP_SHARED, grid_x=dims[0], grid_y=dims[1],
+                                        grid_z=dims[2], local_x=0, local_y=0, local_z=0, max_beams=64,
+                                        max_points=1 << 15))
+    try:
+        rng = np.random.default_rng(5)
+        grid = (rng.random(dims) < 0.02).astype(np.uint8) * 40
+        h.write_map(0, grid)
+        pos, zyx = np.array([5.0, 5.1, 1.6]), np.array([0.2, 0.01, -0.02])
+        params = capi.UpdateParams(10, 100, -3, 0, 3.0)
+        h.set_scan(cloud, rays)
+        h.scan_vote(cloud[rng.integers(0, len(cloud), 500)], pos, zyx)
+        h.update_map(capi.PF_GRID_SHARED, params, pos, zyx)
+        want = grid.copy()
+        O.update_map(O.UpdateCfg(*dims, 0.05, 0, 10, 100, -3, 0, 3.0), want.reshape(-1), pos, zyx, cloud, rays)
+        assert np.array_equal(h.read_map(0), want.reshape(-1))
+    finally:
+        h.close()

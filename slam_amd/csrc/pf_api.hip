@@ -913,6 +913,9 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
         const PfOrderParams op = order_params(h);
         // (sharded: the kernel that writes the local shard's rows counts them)
         const bool count_keys = op.mode != 0 && op.bits == 4;
+        // a second resample with no pf_measure in between: the first one's key counts were never
+        // consumed (pfk_reduce_scores zeroes them) and the fill stage below would add to them
+        if (count_keys) HIP_TRY(h, drop_counted_keys(h));
         HIP_TRY(h, pfk_resample(h->stream, h->cdf, u_dev, h->Pg, h->P, h->offset, bound, h->w, h->logw,
                                 h->pose, h->pose_src, (const double*)poses_global_dev, h->slab ? h->maps : nullptr,
                                 h->slab, (unsigned long long)h->elements, h->draw, h->first, h->dup_anc,
@@ -1078,6 +1081,7 @@ int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const dou
 }
 
 static int grow_scratch(pf_handle* h, size_t need);
+static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
 int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const double pos[3],
                  const double zyx[3], int32_t n_yaw, int32_t yaw_k0, int32_t yaw_kstep,
                  int32_t n_t, double length, int32_t* sums_out, int64_t* best_out) {
@@ -1118,29 +1122,33 @@ int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const dou
     // scratch: matrices, translations, rotated points, sums; kept by the handle and grown on demand
     const size_t nb_m = sizeof(double) * mats.size(), nb_t = sizeof(double) * trans.size();
     const size_t nb_r = sizeof(double) * 3 * (size_t)n_yaw * (size_t)(n_points ? n_points : 1);
-    const size_t nb_s = sizeof(int32_t) * (size_t)nh;
-    if (int rc = grow_scratch(h, nb_m + nb_t + nb_r + nb_s + 64)) return rc;
+    const size_t nb_s = up256(sizeof(int32_t) * (size_t)nh);
+    // the sampled points are staged here too, not in the scan buffers of pf_set_scan: a later
+    // pf_update_map on this handle still marches over the scan it was given
+    const size_t nb_p = sizeof(double) * 3 * (size_t)(n_points ? n_points : 1);
+    if (int rc = grow_scratch(h, nb_m + nb_t + nb_r + nb_s + nb_p + 64)) return rc;
     char* dev = h->vote_scratch;
     double* d_m = (double*)dev; double* d_t = (double*)(dev + nb_m);
     double* d_r = (double*)(dev + nb_m + nb_t); int32_t* d_s = (int32_t*)(dev + nb_m + nb_t + nb_r);
+    double* d_p = (double*)(dev + nb_m + nb_t + nb_r + nb_s);
     std::vector<int32_t> sums((size_t)nh);
     hipError_t e = hipMemcpyAsync(d_m, mats.data(), nb_m, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_t, trans.data(), nb_t, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess && n_points)
-        e = hipMemcpyAsync(h->points, points, sizeof(double) * 3 * (size_t)n_points, hipMemcpyHostToDevice, h->stream);
+        e = hipMemcpyAsync(d_p, points, sizeof(double) * 3 * (size_t)n_points, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         Timed t(h, PF_K_VOTE);
-        e = pfk_scan_vote(h->stream, h->maps, h->points, (int)n_points, d_m, n_yaw, d_t, per, 1 / res,
+        e = pfk_scan_vote(h->stream, h->maps, d_p, (int)n_points, d_m, n_yaw, d_t, per, 1 / res,
                           h->cfg.grid_y, h->cfg.grid_z, h->elements, d_r, d_s);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(sums.data(), d_s, nb_s, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sums.data(), d_s, sizeof(int32_t) * (size_t)nh, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail(h, PF_ERR_HIP, "pf_scan_vote: %s", hipGetErrorString(e));
     int64_t best = -1; int32_t best_sum = 0;                      // S3P:326, 365
     for (int k = 0; k < nh; ++k)
         if (sums[(size_t)k] > best_sum) { best_sum = sums[(size_t)k]; best = k; }
     *best_out = best;
-    if (sums_out) memcpy(sums_out, sums.data(), nb_s);
+    if (sums_out) memcpy(sums_out, sums.data(), sizeof(int32_t) * (size_t)nh);
     return PF_OK;
 }
 
@@ -1155,7 +1163,6 @@ static int grow_scratch(pf_handle* h, size_t need) {
     h->vote_cap = need;
     return PF_OK;
 }
-static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 int pf_sequential_cdf(pf_handle* h, const double* w, int64_t n, int32_t how, double* cdf_out) {
     if (!h) return PF_ERR_ARG;

@@ -630,7 +630,7 @@ __global__ __launch_bounds__(WG) void k3_combine(int nb, const double* __restric
 // normalise, log-weights, CDF: cdf[i+1] = (boff[block] + inclusive scan of raw inside the block) / S.
 // (raw, lb: this thread's raw weight and log-domain twin, loaded by the caller)
 __device__ inline void d3_norm_v(int vb, int lt, double* sh4, int Pg, double raw, double lb, double* w,
-                                 float* __restrict__ logw, const double* prm, const double* boff,
+                                 float* __restrict__ logw, const double* prm, const double boff_vb,
                                  double* cdf, int32_t* __restrict__ first,
                                  unsigned long long* counters) {
     const int g = vb * NB + lt, lane = lt & 63, wv4 = lt >> 6;
@@ -644,7 +644,7 @@ __device__ inline void d3_norm_v(int vb, int lt, double* sh4, int Pg, double raw
     if (g < Pg) {
         w[g] = raw / S;                                     // S3P:936
         logw[g] = (float)(lb - prm[PRM_LSE]);
-        cdf[g + 1] = (boff[vb] + (woff + inc)) / S;
+        cdf[g + 1] = (boff_vb + (woff + inc)) / S;
         first[g] = NEVER_DRAWN;                             // K4's first-occurrence table
     }
     if (g == 0) cdf[0] = 0;
@@ -655,7 +655,7 @@ __device__ inline void d3_norm(int vb, int lt, double* sh4, int Pg, double* w, c
                                double* cdf, int32_t* __restrict__ first,
                                unsigned long long* counters) {
     const int g = vb * NB + lt;
-    d3_norm_v(vb, lt, sh4, Pg, g < Pg ? w[g] : 0.0, g < Pg ? lbuf[g] : 0.0, w, logw, prm, boff, cdf, first,
+    d3_norm_v(vb, lt, sh4, Pg, g < Pg ? w[g] : 0.0, g < Pg ? lbuf[g] : 0.0, w, logw, prm, vb * NB < Pg ? boff[vb] : 0.0, cdf, first,
               counters);
 }
 __global__ __launch_bounds__(NB) void k3_norm(int Pg, double* w, const double* __restrict__ lbuf,
@@ -723,7 +723,7 @@ __device__ __forceinline__ void d3_norm_c(int vb, int Pg, int nb, double* w, con
         prm_s[PRM_LSE] = gmax + log(se);
     }
     __syncthreads();
-    d3_norm_v(vb, lt, sh4, Pg, raw0, lb0, w, logw, prm_s, &s_boff - vb, cdf, first, counters);
+    d3_norm_v(vb, lt, sh4, Pg, raw0, lb0, w, logw, prm_s, s_boff, cdf, first, counters);
 }
 __global__ __launch_bounds__(NB) void k3_norm_c(int Pg, int nb, double* w, const double* lbuf,
                                                 float* __restrict__ logw, const double* bsum,
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(WG) void k4_scan(int nb, const int2* __restrict__ b
 }
 // (a, isd, isf: this thread's draw and its duplicate / free-slot flags, loaded by the caller)
 __device__ inline void d4_scatter_v(int vb, int lt, int* sd4, int* sf4, int a, int isd, int isf, int Pg,
-                                    const int2* boff, int32_t* dup_anc, int32_t* slot_anc) {
+                                    const int2 boff_vb, int32_t* dup_anc, int32_t* slot_anc) {
     const int i = vb * NB + lt, lane = lt & 63, wv4 = lt >> 6;
     const unsigned long long md = __ballot(isd), mf = __ballot(isf);
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -937,7 +937,7 @@ __device__ inline void d4_scatter_v(int vb, int lt, int* sd4, int* sf4, int a, i
     if (lane == 0) { sd4[wv4] = __popcll(md); sf4[wv4] = __popcll(mf); }
     __syncthreads();
     if (i >= Pg) return;                                    // after the last barrier
-    int od = boff[vb].x, of = boff[vb].y;
+    int od = boff_vb.x, of = boff_vb.y;
     for (int k = 0; k < wv4; ++k) { od += sd4[k]; of += sf4[k]; }
     if (isd) dup_anc[od + __popcll(md & below)] = a;
     // a free slot takes the duplicate of its own rank; the apply stage resolves -1-rank -> dup_anc[rank]
@@ -951,7 +951,7 @@ __device__ inline void d4_scatter(int vb, int lt, int* sd4, int* sf4, const int3
     const int a = i < Pg ? draw[i] : 0;
     const int isd = i < Pg && ld_agent(&first[a]) != i;
     const int isf = i < Pg && ld_agent(&first[i]) == NEVER_DRAWN;
-    d4_scatter_v(vb, lt, sd4, sf4, a, isd, isf, Pg, boff, dup_anc, slot_anc);
+    d4_scatter_v(vb, lt, sd4, sf4, a, isd, isf, Pg, vb * NB < Pg ? boff[vb] : make_int2(0, 0), dup_anc, slot_anc);
 }
 __global__ __launch_bounds__(NB) void k4_scatter(const int32_t* __restrict__ draw, int Pg,
                                                  const int32_t* __restrict__ first,
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(NB) void k4_scatter_s(const int32_t* __restrict__ d
     __syncthreads();
     if (lt == 0) my_off = make_int2(sd[0] + sd[1] + sd[2] + sd[3], sf[0] + sf[1] + sf[2] + sf[3]);
     __syncthreads();
-    d4_scatter_v(vb, lt, sd, sf, a0, isd0, isf0, Pg, &my_off - vb, dup_anc, slot_anc);
+    d4_scatter_v(vb, lt, sd, sf, a0, isd0, isf0, Pg, my_off, dup_anc, slot_anc);
 }
 // k_first with the rare sequential-order CDF inside: when draws were ambiguous every workgroup
 // rebuilds the CDF itself (all write the same values) before it searches again.

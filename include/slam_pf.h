@@ -110,6 +110,9 @@ int pf_get_poses(pf_handle* h, double* x, double* y, double* z, double* yaw);
 /* weight vector of ALL n_particles_global particles (S3P:51; every rank holds the whole vector) */
 int pf_set_weights(pf_handle* h, const double* w_global);
 int pf_get_weights(pf_handle* h, double* w_global, float* logw_global /* may be NULL */);
+/* S3P:756: index_high_weight, the global resample() keeps when no weight is above 0 (S3P:815-820).
+ * The handle starts it at 0 like the reference; a host that restores a saved filter sets it here. */
+int pf_set_best_index(pf_handle* h, int32_t index);
 
 /* maps: PER_PARTICLE: slab `i` of the local shard; SHARED: i is ignored. Replaces the reads at
  * S3P:1031-1051 and test set-up. */
@@ -141,7 +144,10 @@ int pf_weights(pf_handle* h, const void* scores_global_dev);
 
 /* ---- resample: S3P:757-821 --------------------------------------------------------------- */
 
-/* u_global: n_particles_global thresholds in draw order (reference parity: the mt19937
+/* Normally called after pf_weights. Called after pf_set_weights instead (no pf_weights in between)
+ * it is the reference's resample() on its own: the CDF is the sequential prefix sum of the weights
+ * as given (S3P:763-767; they need not sum to 1), in the reference's order whatever order_mode says.
+ * u_global: n_particles_global thresholds in draw order (reference parity: the mt19937
  * uniforms of S3P:770-773; systematic resampling: (u0+i)/N), or NULL to reuse the last set.
  * The array is copied before the call returns (into pinned memory the search kernel reads: no
  * device copy is enqueued and the call does not wait for the stream). poses_global_dev: device pointer to the ranks' pose blocks gathered in rank order

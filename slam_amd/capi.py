@@ -29,7 +29,7 @@ SYMBOLS = (
     "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init "
     "pf_ring_default_params pf_ring_init pf_ring_paint pf_ring_update pf_ring_state "
     "pf_depth_to_cloud pf_read_occupied pf_sequential_cdf pfh_draw_indices pfh_vote_epilogue pfh_pose_message pfh_migration_plan "
-    "pfh_update_realtime_pos").split()
+    "pfh_update_realtime_pos pf_set_best_index").split()
 
 
 class Config(C.Structure):
@@ -159,6 +159,9 @@ class Handle:
         w = _c(w, np.float64)
         assert len(w) == self.Pg
         self._ck(lib().pf_set_weights(self._h, _p(w)), "pf_set_weights")
+
+    def set_best_index(self, index):
+        self._ck(lib().pf_set_best_index(self._h, C.c_int32(index)), "pf_set_best_index")
 
     def get_weights(self):
         w = np.empty(self.Pg, np.float64)

@@ -118,6 +118,7 @@ struct pf_handle {
     int M = 0;                         // resident beams
     int n_points = 0, n_rays = 0;
     bool measured = false, weighted = false, have_u = false;
+    bool weights_given = false;        // pf_set_weights since the last resample: pf_resample may run on them alone
     bool exact = true;
     // The shared-grid update (K5) depends on nothing K3/K4 produce, and nothing but K1, K6 and the
     // map accessors read what it writes. pf_update_map(PF_GRID_SHARED) therefore only records the
@@ -557,6 +558,16 @@ int pf_set_weights(pf_handle* h, const double* w) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemcpyAsync(h->w, w, sizeof(double) * (size_t)h->Pg, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->weights_given = true;
+    h->weighted = false;               // a CDF of older weights is stale now
+    return PF_OK;
+}
+
+int pf_set_best_index(pf_handle* h, int32_t index) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, index >= 0 && index < h->Pg, "index outside [0, n_particles_global)");
+    NEED(h, h->rs_issued == h->rs_done, "a pf_resample_async still waits for pf_resample_result");
+    h->best_prev = index;
     return PF_OK;
 }
 
@@ -864,7 +875,8 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
     if (!h) return PF_ERR_ARG;
     if (h->rs_issued - h->rs_done >= 2)
         return fail(h, PF_ERR_STATE, "pf_resample_async: two resamples already wait for pf_resample_result");
-    if (!h->weighted) return fail(h, PF_ERR_STATE, "pf_resample before pf_weights");
+    if (!h->weighted && !h->weights_given)
+        return fail(h, PF_ERR_STATE, "pf_resample before pf_weights (or pf_set_weights)");
     if (!u && !h->have_u) return fail(h, PF_ERR_ARG, "pf_resample: no thresholds resident");
     if (h->Pg != h->P && !poses_global_dev && !h->comm)
         return fail(h, PF_ERR_ARG, "pf_resample: sharded handle needs the gathered pose blocks (or pf_comm_init)");
@@ -908,7 +920,11 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
         // (k + 52) * 2^-53 * cdf[k] * (1 + 1e-9). k_search takes that with 12 % to spare as the band
         // of boundary k (`bound` = the unit roundoff with the factor); it decides how often a step
         // pays for the sequential-order CDF: about once per 1/(8e-17 Pg^3) steps.
-        const double bound = h->exact ? 0.0 : 1.125 * 1.1102230246251565e-16;
+        // resample() on its own (S3P:757-821 on the weights pf_set_weights put there): the CDF is
+        // built in the reference's sequential order, so no draw is ambiguous
+        const bool alone = !h->weighted;
+        if (alone) HIP_TRY(h, pfk_resample_prepare(h->stream, h->w, h->Pg, h->cdf, h->first, h->counters));
+        const double bound = h->exact || alone ? 0.0 : 1.125 * 1.1102230246251565e-16;
         // one GPU, shared-key ordering: the fill stage leaves K1's order keys of the new poses
         const PfOrderParams op = order_params(h);
         // (sharded: the kernel that writes the local shard's rows counts them)
@@ -971,6 +987,7 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
     ++h->rs_issued;
     h->order_dirty = true;
     h->weighted = false;
+    h->weights_given = false;
     h->measured = false;
     return PF_OK;
 }

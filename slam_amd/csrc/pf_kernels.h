@@ -160,6 +160,9 @@ int32_t pfk_result_best(const unsigned long long* slot, int32_t prev);
 // cdf[0] = 0, cdf[i+1] = cdf[i] + w[i] in index order (S3P:763-767), one workgroup: how = 0 the
 // one-lane chain, how = 1 the workgroup scan that gives the same bits (k_cdf_exact_if's form)
 hipError_t pfk_cdf_of(hipStream_t st, const double* w, int n, double* cdf, int how);
+// resample() on its own (weights given by the caller): sequential-order CDF + K4's initial state
+hipError_t pfk_resample_prepare(hipStream_t st, const double* w, int Pg, double* cdf, int32_t* first,
+                                unsigned long long* counters);
 
 // K5: S3P:628-704. rot9: row-major ZYX matrix from the host libm. wpts: double [M][3] scratch.
 struct PfUpdateParams {

@@ -1434,6 +1434,21 @@ int32_t pfk_result_best(const unsigned long long* slot, int32_t prev) {
     return idx >= 0 ? idx : prev;                           // S3P:816: nothing above 0 keeps the previous index
 }
 
+// resample() called on its own (S3P:757-821 on whatever weights the particles hold): what the weight
+// kernels otherwise leave for K4 -- the CDF in the reference's sequential order (S3P:763-767), the
+// first-occurrence table and the counters.
+__global__ __launch_bounds__(NB) void k4_init(int Pg, int32_t* __restrict__ first, unsigned long long* counters) {
+    const int g = blockIdx.x * NB + threadIdx.x;
+    if (g < Pg) first[g] = NEVER_DRAWN;
+    if (g < 3) counters[g] = 0;
+}
+hipError_t pfk_resample_prepare(hipStream_t st, const double* w, int Pg, double* cdf, int32_t* first,
+                                unsigned long long* counters) {
+    hipLaunchKernelGGL(k_cdf_of, dim3(1), dim3(WG), 0, st, w, Pg, cdf, Pg > 2048 ? 1 : 0);
+    hipLaunchKernelGGL(k4_init, dim3(nblocks(Pg)), dim3(NB), 0, st, Pg, first, counters);
+    return hipGetLastError();
+}
+
 hipError_t pfk_cdf_of(hipStream_t st, const double* w, int n, double* cdf, int how) {
     hipLaunchKernelGGL(k_cdf_of, dim3(1), dim3(WG), 0, st, w, n, cdf, how);
     return hipGetLastError();

@@ -204,6 +204,30 @@ int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const dou
                  const double zyx[3], int32_t n_yaw, int32_t yaw_k0, int32_t yaw_kstep,
                  int32_t n_t, double length, int32_t* sums_out, int64_t* best_out);
 
+/* ---- the scan vote for callers that cannot allocate ------------------------------------------
+ * No counterpart in the reference (its scan_localization() works on class members, S3P:293-295).
+ * For callers that may not call hipMalloc or wait: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid allocation. Same arithmetic and kernels as pf_scan_vote, no handle:
+ * the caller passes the inputs and the output as DEVICE pointers -- grid_dev: uint8 [gx*gy*gz] in the
+ * reference's order (S3P:81-83); points_dev: double [n_points][3] sensor-frame points; sums_dev:
+ * int32 [n_yaw*n_t^3], the per-hypothesis counts in loop order r, x, y, z (first strict maximum above
+ * 0 = the reference's choice, S3P:365) -- and the kernels' scratch (rotation matrices, translations,
+ * rotated points) is a fixed 1.7 MiB device array inside the library, one per GPU, held until the
+ * process ends. Hence the limits: n_points <= PF_STATIC_MAX_POINTS, n_yaw <= PF_STATIC_MAX_YAW,
+ * n_t <= PF_STATIC_MAX_T; beyond them PF_ERR_ARG (text via pf_last_error(NULL)). The call allocates
+ * nothing, copies nothing between host and device and does not synchronise: it enqueues three
+ * kernels on hip_stream (NULL = the default stream) of `device` and returns. Every call on a GPU
+ * uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) race; calls
+ * ordered on one stream do not. Nothing in the array needs clearing between calls (each call
+ * rewrites what it reads). */
+#define PF_STATIC_MAX_POINTS 4096
+#define PF_STATIC_MAX_YAW    16
+#define PF_STATIC_MAX_T      8
+int pf_scan_vote_static(int32_t device, void* hip_stream, const uint8_t* grid_dev, int32_t gx, int32_t gy,
+                        int32_t gz, double resolution, const double* points_dev, int64_t n_points,
+                        const double pos[3], const double zyx[3], int32_t n_yaw, int32_t yaw_k0,
+                        int32_t yaw_kstep, int32_t n_t, double length, int32_t* sums_dev);
+
 /* ---- plumbing ------------------------------------------------------------------------------ */
 void* pf_stream(pf_handle* h);                           /* the hipStream_t the handle works on */
 /* ---- keyframe ring of the localisation grid: S3P:286-289, 305-312, 419-529 -------------------

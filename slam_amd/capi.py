@@ -29,7 +29,7 @@ SYMBOLS = (
     "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init "
     "pf_ring_default_params pf_ring_init pf_ring_paint pf_ring_update pf_ring_state "
     "pf_depth_to_cloud pf_read_occupied pf_sequential_cdf pfh_draw_indices pfh_vote_epilogue pfh_pose_message pfh_migration_plan "
-    "pfh_update_realtime_pos pf_set_best_index").split()
+    "pfh_update_realtime_pos pf_set_best_index pf_scan_vote_static").split()
 
 
 class Config(C.Structure):
@@ -482,6 +482,19 @@ def migration_plan(slot_anc, n_local, rank):
                                      _p(sq), C.byref(ns), _p(rd), _p(rp), _p(rq), C.byref(nr), C.c_int64(cap))
     return (total, list(zip(ss[:ns.value].tolist(), sp[:ns.value].tolist(), sq[:ns.value].tolist())),
             list(zip(rd[:nr.value].tolist(), rp[:nr.value].tolist(), rq[:nr.value].tolist())))
+
+
+def scan_vote_static(device, stream, grid_ptr, dims, resolution, points_ptr, n_points, pos, zyx, sums_ptr,
+                     n_yaw=5, yaw_k0=-6, yaw_kstep=3, n_t=5, length=0.25):
+    """pf_scan_vote_static: device pointers in and out (ints), nothing allocated. Raises PfError."""
+    pos = _c(pos, np.float64); zyx = _c(zyx, np.float64)
+    rc = lib().pf_scan_vote_static(C.c_int32(device), C.c_void_p(stream), C.c_void_p(grid_ptr), C.c_int32(dims[0]),
+                                   C.c_int32(dims[1]), C.c_int32(dims[2]), C.c_double(resolution),
+                                   C.c_void_p(points_ptr), C.c_int64(n_points), _p(pos), _p(zyx), C.c_int32(n_yaw),
+                                   C.c_int32(yaw_k0), C.c_int32(yaw_kstep), C.c_int32(n_t), C.c_double(length),
+                                   C.c_void_p(sums_ptr))
+    if rc != PF_OK:
+        raise PfError(f"pf_scan_vote_static -> {rc}: {lib().pf_last_error(None).decode()}")
 
 
 def comm_unique_id():

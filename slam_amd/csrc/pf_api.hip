@@ -23,6 +23,8 @@ struct EventPair { hipEvent_t a, b; };
 
 }  // namespace
 
+void pfk_set_global_error(const char* text) { g_create_error = text ? text : ""; }
+
 struct pf_handle {
     pf_config cfg;
     hipStream_t stream = nullptr;      // the stream in use (own_stream or the caller's)

@@ -159,6 +159,8 @@ static inline size_t pfk_result_slot_bytes(int Pg) {
 int32_t pfk_result_best(const unsigned long long* slot, int32_t prev);
 // cdf[0] = 0, cdf[i+1] = cdf[i] + w[i] in index order (S3P:763-767), one workgroup: how = 0 the
 // one-lane chain, how = 1 the workgroup scan that gives the same bits (k_cdf_exact_if's form)
+// text pf_last_error(NULL) returns (errors of calls that have no handle)
+void pfk_set_global_error(const char* text);
 hipError_t pfk_cdf_of(hipStream_t st, const double* w, int n, double* cdf, int how);
 // resample() on its own (weights given by the caller): sequential-order CDF + K4's initial state
 hipError_t pfk_resample_prepare(hipStream_t st, const double* w, int Pg, double* cdf, int32_t* first,

@@ -49,9 +49,15 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="read every step's results before the next step is enqueued (pf_resample) instead of "
                          "one step later (pf_resample_async / pf_resample_result)")
-    ap.add_argument("--fresh-thresholds", action="store_true",
-                    help="hand pf_resample new thresholds every step (the reference draws them per step, "
-                         "S3P:769) instead of keeping one set resident: 8 B per particle uploaded per step")
+    ap.add_argument("--resident-thresholds", action="store_true",
+                    help="keep one set of resampling thresholds resident instead of handing pf_resample new ones "
+                         "every step (the default, as the reference draws them per step, S3P:769: 8 B per "
+                         "particle per step)")
+    ap.add_argument("--static-sensor", action="store_true",
+                    help="K5 from the same sensor pose every step (cells saturate at their clamps) instead of "
+                         "a pose that moves along a loop")
+    ap.add_argument("--profile-steps", type=int, default=20,
+                    help="steps of the second, untimed pass that times K3/K4/K5 with HIP events (0: skip)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal: use the multi-GPU code path (RCCL all-gathers) even at N=1")
     return ap.parse_args()
@@ -130,8 +136,40 @@ def k1_traffic(P, M, grid):
     return t["traffic_bytes_per_launch"]
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` launched plainly: one child process per GPU, started before this
+    process has touched the GPU, the same rank environment torch.distributed.run would set. Rank 0's
+    stdout (the one JSON line) passes through."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = pr.wait() or rc
+    sys.exit(rc)
+
+
+def update_traffic(sc, pos_list, res=0.05, max_range=3.0):
+    """Algorithmic bytes of one K5 launch: 24 B per endpoint + 2 B per visited voxel
+    (hits within range + the steps of every ray, S3P:676-685), averaged over the sensor poses."""
+    pts = sc["points"]; n = np.linalg.norm(pts, axis=1)
+    rays = n[sc["ray_idx"]]
+    steps = np.maximum(np.rint(rays / res) - 1, 0).sum()
+    hits = int((n <= max_range).sum())
+    return 24.0 * len(pts) + 2.0 * (hits + steps)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     import torch
     import torch.distributed as dist
     from slam_amd import capi, synth
@@ -140,10 +178,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = world
+    a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -183,9 +218,14 @@ def main():
     h.set_beams(*sc["beams"])
     h.set_scan(sc["points"], sc["ray_idx"])
     u = capi.draw_uniform(3, Pg)                     # the same thresholds on every rank
-    u_fresh = [capi.draw_uniform(100 + k, Pg) for k in range(8)] if a.fresh_thresholds else None
+    u_fresh = None if a.resident_thresholds else [capi.draw_uniform(100 + k, Pg) for k in range(8)]
     upd = capi.UpdateParams(10, 100, -3, 0, 3.0)
-    pos = tp[:3].copy(); zyx = np.array([tp[3], 0.0, 0.0])
+    # the sensor of the map update moves along a loop (0.5 m radius, 2 cm and 0.01 rad per step), so
+    # K5 keeps meeting cells that are not yet at their clamps; identical on every rank
+    NPOSE = 1 if a.static_sensor else 157
+    ang = 2 * np.pi * np.arange(NPOSE) / NPOSE
+    sensor_pos = [tp[:3] + (0.0 if a.static_sensor else 0.5) * np.array([np.cos(t) - 1.0, np.sin(t), 0.0]) for t in ang]
+    sensor_zyx = [np.array([tp[3] + (0.0 if a.static_sensor else 0.01 * k), 0.0, 0.0]) for k in range(NPOSE)]
     # predicted pose blocks (S3P:911-914 outcome), resident in HBM: NBLK different noise draws
     NBLK = 8
     blocks = torch.empty((NBLK, 9, P), dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -203,7 +243,7 @@ def main():
         be.measure(0)
         if not a.no_update:
             # the grid update only has to follow this step's measure and precede the next one
-            h.update_map(capi.PF_GRID_SHARED, upd, pos, zyx)
+            h.update_map(capi.PF_GRID_SHARED, upd, sensor_pos[step_no[0] % NPOSE], sensor_zyx[step_no[0] % NPOSE])
         h.predict_device(block_ptrs[step_no[0] % NBLK])
         step_no[0] += 1
         be.weights()
@@ -253,9 +293,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     k1_ms, k1_n = h.kernel_time(capi.PF_K_MEASURE)
-    k3_ms, k3_n = h.kernel_time(capi.PF_K_WEIGHTS)
-    k4_ms, k4_n = h.kernel_time(capi.PF_K_RESAMPLE)
-    k5_ms, k5_n = h.kernel_time(capi.PF_K_UPDATE)
+    ko_ms, ko_n = 0.0, 0
+    k3_ms = k4_ms = k5_ms = 0.0
+    k3_n = k4_n = k5_n = 0
+    moved = 0
+    if a.profile_steps > 0:
+        # second, untimed pass: HIP events around K3, K4 and K5 as well (eight more event records per
+        # step cost ~20 us of host time, so not in the timed region); K5 runs on its own here (in the
+        # timed region it rides in K3's launches)
+        if a.time_all_kernels:
+            k3_ms, k3_n = h.kernel_time(capi.PF_K_WEIGHTS); k4_ms, k4_n = h.kernel_time(capi.PF_K_RESAMPLE)
+            k5_ms, k5_n = h.kernel_time(capi.PF_K_UPDATE)
+        h.profile(True, [capi.PF_K_WEIGHTS, capi.PF_K_RESAMPLE, capi.PF_K_UPDATE, capi.PF_K_ORDER])
+        for i in range(a.profile_steps):
+            be.measure(0)
+            if not a.no_update:
+                h.update_map(capi.PF_GRID_SHARED, upd, sensor_pos[step_no[0] % NPOSE], sensor_zyx[step_no[0] % NPOSE])
+                h.synchronize()                              # runs the recorded update now, alone
+            h.predict_device(block_ptrs[step_no[0] % NBLK])
+            step_no[0] += 1
+            be.weights()
+            slots, _, _, _ = be.resample(thresholds(), want_slots=True)
+            moved += int((slots != np.arange(Pg)).sum())
+        fence()
+        h.profile(False)
+        a3, b3 = h.kernel_time(capi.PF_K_WEIGHTS); a4, b4 = h.kernel_time(capi.PF_K_RESAMPLE)
+        a5, b5 = h.kernel_time(capi.PF_K_UPDATE)
+        ko_ms, ko_n = h.kernel_time(capi.PF_K_ORDER)
+        ko_n = a.profile_steps                               # two launches per step (ordering, score reduction)
+        k3_ms += a3; k3_n += b3; k4_ms += a4; k4_n += b4; k5_ms += a5; k5_n += b5
 
     if rank == 0:
         evals = float(Pg) * M * a.steps
@@ -275,7 +341,8 @@ def main():
                        "particles_per_gpu": P, "particles_total": Pg, "beams": M,
                        "grid": list(dims), "order": "fast" if Pg > 2048 else "exact",
                        "collectives": ("rccl in-library" if getattr(be, "native", False) else "torch.distributed nccl") if sharded else "none",
-                       "thresholds": "new every step, uploaded" if a.fresh_thresholds else "resident",
+                       "thresholds": "resident" if a.resident_thresholds else "new every step (S3P:769), staged in pinned memory",
+                       "sensor": "static" if a.static_sensor else f"moves along a {NPOSE}-pose loop",
                        "results_read": "every step, before the next is enqueued" if a.no_pipeline
                                        else "every step, one step late (pf_resample_async)",
                        "ambiguous_draws": int(amb_total), "nohit_draws": int(nohit_total)},
@@ -284,9 +351,31 @@ def main():
                          "traffic": k1_traffic(P, M, a.grid), "algorithmic_bytes_per_launch": k1_bytes,
                          "avg_launch_us": k1_avg_s * 1e6, "launches": int(k1_n),
                          "k1_evals_per_s": P * M / k1_avg_s if k1_avg_s > 0 else 0.0},
-            "kernel_us": {"measure": k1_ms / max(k1_n, 1) * 1e3, "weights": k3_ms / max(k3_n, 1) * 1e3,
-                          "resample": k4_ms / max(k4_n, 1) * 1e3, "update": k5_ms / max(k5_n, 1) * 1e3},
         }
+        # the measure stage as a whole: lane ordering + K1 + score reduction (they exist only for K1)
+        stage_s = (k1_ms / max(k1_n, 1) + ko_ms / max(ko_n, 1)) * 1e-3
+        out["roofline"]["measure_stage_us"] = stage_s * 1e6
+        out["roofline"]["measure_stage_frac"] = k1_bytes / stage_s / 8e12 if stage_s > 0 else 0.0
+        ku = {"measure": k1_ms / max(k1_n, 1) * 1e3, "order_and_reduce": ko_ms / max(ko_n, 1) * 1e3}
+        other = {}
+        if k3_n:
+            ku["weights"] = k3_ms / k3_n * 1e3
+            b3 = 28.0 * Pg                                   # 16 P in + 12 P out
+            other["weights"] = {"bytes": b3, "achieved": b3 / (k3_ms / k3_n * 1e-3) / 1e9, "unit": "GB/s",
+                                "frac": b3 / (k3_ms / k3_n * 1e-3) / 8e12}
+        if k4_n:
+            ku["resample"] = k4_ms / k4_n * 1e3
+            b4 = 20.0 * Pg + 40.0 * moved / max(a.profile_steps, 1)   # 16 P in + 4 P out + 40 B per replaced slot
+            other["resample"] = {"bytes": b4, "achieved": b4 / (k4_ms / k4_n * 1e-3) / 1e9, "unit": "GB/s",
+                                 "frac": b4 / (k4_ms / k4_n * 1e-3) / 8e12,
+                                 "replaced_slots_per_step": moved / max(a.profile_steps, 1)}
+        if k5_n:
+            ku["update"] = k5_ms / k5_n * 1e3
+            b5 = update_traffic(sc, sensor_pos)
+            other["update"] = {"bytes": b5, "achieved": b5 / (k5_ms / k5_n * 1e-3) / 1e9, "unit": "GB/s",
+                               "frac": b5 / (k5_ms / k5_n * 1e-3) / 8e12}
+        out["kernel_us"] = ku
+        out["roofline_other_kernels"] = other
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, dims, P, M, a.cpu_seconds)
         print(json.dumps(out), flush=True)

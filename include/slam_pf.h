@@ -49,7 +49,8 @@ extern "C" {
 #define PF_K_RESAMPLE  2
 #define PF_K_UPDATE    3
 #define PF_K_VOTE      4
-#define PF_K_COUNT     5
+#define PF_K_ORDER     5   /* K1's lane ordering + score reduction (two launches per pf_measure) */
+#define PF_K_COUNT     6
 
 typedef struct pf_handle pf_handle;
 

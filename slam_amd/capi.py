@@ -15,7 +15,7 @@ PF_OK = 0
 PF_MAP_SHARED, PF_MAP_PER_PARTICLE = 0, 1
 PF_ORDER_AUTO, PF_ORDER_EXACT, PF_ORDER_FAST = 0, 1, 2
 PF_GRID_SHARED, PF_GRID_LOCAL = 0, 1
-PF_K_MEASURE, PF_K_WEIGHTS, PF_K_RESAMPLE, PF_K_UPDATE, PF_K_VOTE = 0, 1, 2, 3, 4
+PF_K_MEASURE, PF_K_WEIGHTS, PF_K_RESAMPLE, PF_K_UPDATE, PF_K_VOTE, PF_K_ORDER = 0, 1, 2, 3, 4, 5
 
 # every symbol include/slam_pf.h declares (tests check the library exports exactly these)
 SYMBOLS = (

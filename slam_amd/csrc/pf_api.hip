@@ -754,6 +754,7 @@ int pf_measure(pf_handle* h, int add_points) {
     const PfOrderParams op = order_params(h);
     const bool small_keys = op.mode != 0 && op.bits == 4;      // 4096 buckets: fixed counter pair
     if (!fuse && !h->force_exact_measure && h->order_dirty) {
+        Timed t(h, PF_K_ORDER);
         if (small_keys) {
             HIP_TRY(h, pfk_order(h->stream, h->pose, h->P, h->order_keys, h->order_hist[0], h->order_hist[1],
                                  h->order, h->sorted, op, h->hist_counted));
@@ -794,8 +795,11 @@ int pf_measure(pf_handle* h, int add_points) {
                                         h->beams_occ, Mk, chunks, bpc, grid_params(h), h->lmax_occ,
                                         h->order, h->partial));
     }
-    HIP_TRY(h, pfk_reduce_scores(h->stream, h->partial, chunks, h->P, h->scores, h->bmin, h->order_hist[0],
-                                 h->order_hist[1], small_keys ? 4096 : 0));
+    {
+        Timed t(h, PF_K_ORDER);
+        HIP_TRY(h, pfk_reduce_scores(h->stream, h->partial, chunks, h->P, h->scores, h->bmin, h->order_hist[0],
+                                     h->order_hist[1], small_keys ? 4096 : 0));
+    }
     h->measured = true;
     return PF_OK;
 }

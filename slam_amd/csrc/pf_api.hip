@@ -57,6 +57,17 @@ struct pf_handle {
     PfBeamF* beams_occ_f = nullptr;    // [max_beams] the same in fp32
     PfColG* beams_col = nullptr;       // [max_beams] the same grouped by local column (k_measure_col)
     std::vector<PfColG> h_cols;
+    // k_measure_box: the same groups ordered by cluster, the clusters ordered by blockIdx.y group
+    PfColG* beams_colc = nullptr;      // [max_beams]
+    PfCluster* clusters = nullptr;     // [max_beams]
+    int* group_start = nullptr;        // [257]
+    std::vector<PfColG> h_colc;
+    std::vector<PfCluster> h_clusters;
+    std::vector<int> h_group_start;
+    int box_kp = 1, box_parts = 1, box_lp = 1, box_groups = 0;   // pfk_box_plan; groups 0 = no plan
+    int partial_rows = 1;              // rows of `partial` (chunks of the col kernels / groups of the box kernel)
+    int k1_mode = 0;                   // SLAM_PF_K1: 0 auto, 1 col (gather layout), 2 box (LDS) whenever possible
+    double yaw_hint = 0.0;             // mean yaw of the last host-side predict: aligns the clusters with the grid
     int n_cols = 0;
     int col_ends[4] = {0, 0, 0, 0};    // ends of the 4-, 3-, 2-, 1-beam groups in beams_col
     int M_occ = 0;                     // padded to a multiple of PF_BEAM_GROUP
@@ -279,6 +290,9 @@ void upload_pose_rows(pf_handle* h, const double* x, const double* y, const doub
     const int P = h->P;
     double* hp = h->h_pose.data();
     const double res = h->cfg.resolution;
+    double ysum = 0;
+    for (int i = 0; i < P; ++i) ysum += yaw[i];
+    h->yaw_hint = ysum / P;
     for (int i = 0; i < P; ++i) {
         hp[0 * (size_t)P + i] = x[i];
         hp[1 * (size_t)P + i] = y[i];
@@ -290,6 +304,97 @@ void upload_pose_rows(pf_handle* h, const double* x, const double* y, const doub
         hp[7 * (size_t)P + i] = y[i] * 1 / res;
         hp[8 * (size_t)P + i] = z[i] * 1 / res;
     }
+}
+
+// Clusters of beams for k_measure_box: recursive median splits of the occupied beams along their
+// longest extent (in a frame turned by the cloud's mean yaw, so that wall pieces are thin boxes of
+// the grid) until the box a cluster needs -- its extent plus the margin a particle cloud typically
+// adds -- fits the LDS buffer with room to spare; inside a cluster the beams of one local column
+// form groups of up to four (x and y are evaluated once per group); then the clusters are dealt
+// to the blockIdx.y groups, largest first onto the least loaded one. SLAM_PF_BOX=volume,mx,my,mz
+// overrides the budget (cells) and the margins (development knob). Any clustering gives the same
+// results; it only decides how much a workgroup stages per evaluation.
+void build_clusters(pf_handle* h, int n_occ) {
+    h->box_groups = 0;
+    h->h_colc.clear(); h->h_clusters.clear(); h->h_group_start.clear();
+    if (n_occ == 0 || h->cfg.map_mode != PF_MAP_SHARED || h->cfg.grid_z % 4 != 0) return;
+    double vol = 20000, mx = 12, my = 12, mz = 6;
+    if (const char* e = getenv("SLAM_PF_BOX")) (void)sscanf(e, "%lf,%lf,%lf,%lf", &vol, &mx, &my, &mz);
+    const double c0 = cos(h->yaw_hint), s0 = sin(h->yaw_hint);
+    struct Ref { float u, v, z; int idx; };
+    std::vector<Ref> r((size_t)n_occ);
+    for (int i = 0; i < n_occ; ++i) {
+        const PfBeam& b = h->h_beams_occ[(size_t)i];
+        r[(size_t)i] = Ref{(float)(c0 * b.lx - s0 * b.ly), (float)(s0 * b.lx + c0 * b.ly), (float)b.lz, i};
+    }
+    struct Span { int a, b; };
+    std::vector<Span> todo{{0, n_occ}}, done;
+    while (!todo.empty()) {
+        const Span sp = todo.back(); todo.pop_back();
+        float u0 = r[(size_t)sp.a].u, u1 = u0, v0 = r[(size_t)sp.a].v, v1 = v0, z0 = r[(size_t)sp.a].z, z1 = z0;
+        for (int i = sp.a + 1; i < sp.b; ++i) {
+            const Ref& q = r[(size_t)i];
+            u0 = std::min(u0, q.u); u1 = std::max(u1, q.u); v0 = std::min(v0, q.v); v1 = std::max(v1, q.v);
+            z0 = std::min(z0, q.z); z1 = std::max(z1, q.z);
+        }
+        const double eu = u1 - u0, ev = v1 - v0, ez = z1 - z0;
+        // (at most 256 column groups per cluster, BOX_COLCAP: every beam could be a group of its own)
+        if (sp.b - sp.a <= 1 || ((eu + mx) * (ev + my) * (ez + mz) <= vol && sp.b - sp.a <= 256)) { done.push_back(sp); continue; }
+        const int mid = (sp.a + sp.b) / 2;
+        auto first = r.begin() + sp.a, last = r.begin() + sp.b, nth = r.begin() + mid;
+        if (eu >= ev && eu >= ez) std::nth_element(first, nth, last, [](const Ref& a, const Ref& b) { return a.u < b.u; });
+        else if (ev >= ez) std::nth_element(first, nth, last, [](const Ref& a, const Ref& b) { return a.v < b.v; });
+        else std::nth_element(first, nth, last, [](const Ref& a, const Ref& b) { return a.z < b.z; });
+        todo.push_back(Span{sp.a, mid}); todo.push_back(Span{mid, sp.b});
+    }
+    const int nc = (int)done.size();
+    pfk_box_plan(h->P, nc, &h->box_kp, &h->box_parts, &h->box_lp, &h->box_groups);
+    // largest cluster first onto the least loaded group
+    std::vector<int> by_size((size_t)nc);
+    for (int c = 0; c < nc; ++c) by_size[(size_t)c] = c;
+    auto size_of = [&](int c) { return done[(size_t)c].b - done[(size_t)c].a; };
+    std::sort(by_size.begin(), by_size.end(), [&](int a, int b) { return size_of(a) != size_of(b) ? size_of(a) > size_of(b) : a < b; });
+    const int G = h->box_groups;
+    std::vector<long long> load((size_t)G, 0);
+    std::vector<std::vector<int>> members((size_t)G);
+    for (int c : by_size) {
+        int best = 0;
+        for (int g = 1; g < G; ++g) if (load[(size_t)g] < load[(size_t)best]) best = g;
+        load[(size_t)best] += size_of(c) + 4;               // a cluster costs a staging round besides its beams
+        members[(size_t)best].push_back(c);
+    }
+    std::vector<int> ids;
+    h->h_group_start.push_back(0);
+    for (int g = 0; g < G; ++g) {
+        for (int c : members[(size_t)g]) {
+            ids.clear();
+            for (int i = done[(size_t)c].a; i < done[(size_t)c].b; ++i) ids.push_back(r[(size_t)i].idx);
+            std::sort(ids.begin(), ids.end());              // the list's own order: x, y, z ascending (S3P:868)
+            PfCluster pc{};
+            pc.g0 = (int)h->h_colc.size();
+            pc.lx0 = pc.ly0 = 3.0e38f; pc.lx1 = pc.ly1 = -3.0e38f; pc.lz0 = INT32_MAX; pc.lz1 = INT32_MIN;
+            for (size_t j = 0; j < ids.size();) {
+                const PfBeam& b0 = h->h_beams_occ[(size_t)ids[j]];
+                PfColG q{};
+                q.lx = (float)b0.lx; q.ly = (float)b0.ly; q.n = 0;
+                while (j < ids.size() && q.n < 4 && h->h_beams_occ[(size_t)ids[j]].lx == b0.lx &&
+                       h->h_beams_occ[(size_t)ids[j]].ly == b0.ly)
+                    q.lz[q.n++] = (int32_t)h->h_beams_occ[(size_t)ids[j++]].lz;
+                std::sort(q.lz, q.lz + q.n);
+                for (int k = q.n; k < 4; ++k) q.lz[k] = q.lz[q.n - 1];
+                h->h_colc.push_back(q);
+                pc.lx0 = std::min(pc.lx0, q.lx); pc.lx1 = std::max(pc.lx1, q.lx);
+                pc.ly0 = std::min(pc.ly0, q.ly); pc.ly1 = std::max(pc.ly1, q.ly);
+                pc.lz0 = std::min(pc.lz0, q.lz[0]); pc.lz1 = std::max(pc.lz1, q.lz[q.n - 1]);
+            }
+            pc.g1 = (int)h->h_colc.size();
+            h->h_clusters.push_back(pc);
+        }
+        h->h_group_start.push_back((int)h->h_clusters.size());
+    }
+    if (getenv("SLAM_PF_BOX_STATS"))
+        fprintf(stderr, "build_clusters: %d occupied beams -> %d clusters, %zu column groups, %d groups\n", n_occ, nc,
+                h->h_colc.size(), G);
 }
 
 }  // namespace
@@ -318,7 +423,7 @@ void pf_destroy(pf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->bmin_all, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_col,
+    void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->bmin_all, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_col, h->beams_colc, h->clusters, h->group_start,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
                     h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -435,11 +540,16 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->beams_occ, (size_t)c.max_beams + PF_BEAM_GROUP));
     CREATE_TRY(dalloc(&h->beams_occ_f, (size_t)c.max_beams + PF_BEAM_GROUP));
     CREATE_TRY(dalloc(&h->beams_col, (size_t)c.max_beams + 1));
+    CREATE_TRY(dalloc(&h->beams_colc, (size_t)c.max_beams + 1));
+    CREATE_TRY(dalloc(&h->clusters, (size_t)c.max_beams + 1));
+    CREATE_TRY(dalloc(&h->group_start, (size_t)257));
+    if (const char* e = getenv("SLAM_PF_K1")) h->k1_mode = !strcmp(e, "col") ? 1 : !strcmp(e, "box") ? 2 : 0;
     if (const char* e = getenv("SLAM_PF_TWO_GATHERS")) h->group_gathers = atoi(e) == 0;
     if (const char* e = getenv("SLAM_PF_CHUNKS")) h->tune_chunks = atoi(e);
     if (h->tune_chunks > h->max_chunks) h->max_chunks = h->tune_chunks < 1024 ? h->tune_chunks : 1024;
     if (const char* e = getenv("SLAM_PF_EXACT_MEASURE")) h->force_exact_measure = atoi(e);
-    CREATE_TRY(dalloc(&h->partial, (size_t)h->max_chunks * P));
+    h->partial_rows = std::max(h->max_chunks, 256 / (((int)P + 4095) / 4096));
+    CREATE_TRY(dalloc(&h->partial, (size_t)h->partial_rows * P));
     CREATE_TRY(dalloc(&h->scores, P));
     CREATE_TRY(dalloc(&h->bmin, (P + 63) / 64));
     CREATE_TRY(dalloc(&h->draw, Pg));
@@ -688,6 +798,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         for (int k = g.n; k < 4; ++k) g.lz[k] = g.lz[g.n - 1];
         h->h_cols.push_back(g);
     }
+    build_clusters(h, n_real_occ);
     // ... and inside a phase by range: how far the lanes of a wave spread over cache lines grows
     // with the beam's range, so neighbours in this order cost about the same and go to different chunks
     std::stable_sort(h->h_cols.begin(), h->h_cols.end(), [](const PfColG& a, const PfColG& b) {
@@ -705,6 +816,14 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     if (h->n_cols)
         HIP_TRY(h, hipMemcpyAsync(h->beams_col, h->h_cols.data(), sizeof(PfColG) * h->h_cols.size(),
                                   hipMemcpyHostToDevice, h->stream));
+    if (h->box_groups > 0) {
+        HIP_TRY(h, hipMemcpyAsync(h->beams_colc, h->h_colc.data(), sizeof(PfColG) * h->h_colc.size(),
+                                  hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->clusters, h->h_clusters.data(), sizeof(PfCluster) * h->h_clusters.size(),
+                                  hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->group_start, h->h_group_start.data(), sizeof(int) * h->h_group_start.size(),
+                                  hipMemcpyHostToDevice, h->stream));
+    }
     if (no) {
         HIP_TRY(h, hipMemcpyAsync(h->beams_occ, h->h_beams_occ.data(), sizeof(PfBeam) * no,
                                   hipMemcpyHostToDevice, h->stream));
@@ -722,8 +841,17 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
 // K1 lane order: Morton key over (yaw, x/res, y/res) in cells of 1/200 rad and 1/3 voxel; 4 bits
 // per axis sort 64-lane waves finely enough up to 64k particles per handle, 5 bits beyond.
 // SLAM_PF_ORDER=qa,qx,qy,mode,bits overrides (development knob).
+static bool box_eligible(const pf_handle* h) {
+    // opt-in (SLAM_PF_K1=box): measured slower than the gather-layout kernel at every BASELINE size so
+    // far (the per-cluster barrier makes every wave wait for the one with the most
+    // fp64-corrected columns, and the sparse bench scan stages 15 KB per nine beams)
+    return h->cfg.map_mode == PF_MAP_SHARED && h->cfg.grid_z % 4 == 0 && !h->force_exact_measure && h->k1_mode == 2;
+}
 static PfOrderParams order_params(const pf_handle* h) {
     PfOrderParams op{200.0, 3.0, 3.0, 1, h->P <= 65536 ? 4 : 5};
+    // k_measure_box wants its workgroups' particles close in yaw (the box of a cluster grows with
+    // range x yaw span): yaw-major keys, 1/400 rad and one-voxel cells
+    if (box_eligible(h)) op = PfOrderParams{400.0, 1.0, 1.0, 2, 4};
     if (const char* e = getenv("SLAM_PF_ORDER")) {
         double a, x, y; int m, b;
         if (sscanf(e, "%lf,%lf,%lf,%d,%d", &a, &x, &y, &m, &b) == 5 && (b == 4 || b == 5))
@@ -767,14 +895,22 @@ int pf_measure(pf_handle* h, int add_points) {
     }
     h->hist_counted = false;           // consumed above, or stale: pfk_reduce_scores zeroes the pair
     HIP_TRY(h, wait_map_writes(h));      // the ordering above may overlap a running K5, K1 may not
-    const bool swz = h->shadow && !fuse && !h->force_exact_measure;
+    // LDS-staged boxes of the reference-order grid on request (SLAM_PF_K1=box); else the gather layout
+    const bool box = !fuse && h->box_groups > 0 && box_eligible(h);
+    const bool swz = h->shadow && !fuse && !h->force_exact_measure && !box;
     if (swz && h->shadow_dirty) {
         HIP_TRY(h, pfk_swz_build(h->stream, h->maps, h->shadow, h->swz));
         h->shadow_dirty = false;
     }
     {
         Timed t(h, PF_K_MEASURE);
-        if (swz) {
+        if (box) {
+            chunks = h->box_groups;
+            HIP_TRY(h, pfk_measure_box(h->stream, h->sorted, h->P, h->maps, h->cfg.grid_x, h->cfg.grid_y, h->cfg.grid_z,
+                                       h->beams_colc, h->clusters, h->group_start, h->box_kp, h->box_parts, h->box_lp,
+                                       h->box_groups, grid_params(h), h->lmax_occ, h->partial));
+        }
+        else if (swz) {
             // >= 12 groups (about 32 beams) per chunk, like min_bpc above
             int cch = h->tune_chunks > 0 ? h->tune_chunks : h->max_chunks;
             if (cch > h->max_chunks) cch = h->max_chunks;
@@ -797,6 +933,10 @@ int pf_measure(pf_handle* h, int add_points) {
     }
     {
         Timed t(h, PF_K_ORDER);
+        if (box || swz)
+            HIP_TRY(h, pfk_reduce_scores_l(h->stream, h->partial, chunks, h->P, h->order, h->scores, h->bmin,
+                                           h->order_hist[0], h->order_hist[1], small_keys ? 4096 : 0));
+        else
         HIP_TRY(h, pfk_reduce_scores(h->stream, h->partial, chunks, h->P, h->scores, h->bmin, h->order_hist[0],
                                      h->order_hist[1], small_keys ? 4096 : 0));
     }

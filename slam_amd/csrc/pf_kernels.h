@@ -33,6 +33,14 @@ struct __attribute__((aligned(32))) PfColG {
     int32_t lz[4];
 };
 
+// A spatially compact cluster of column groups for k_measure_box (32 B, one scalar load): its groups
+// cg[g0 .. g1) and the bounds of their local coordinates.
+struct __attribute__((aligned(32))) PfCluster {
+    int32_t g0, g1;
+    float lx0, lx1, ly0, ly1;
+    int32_t lz0, lz1;
+};
+
 // Pose block: double [PF_POSE_ROWS][n] = x, y, z, yaw, cos, sin, x/res, y/res, z/res.
 #define PF_POSE_ROWS 9
 
@@ -63,7 +71,7 @@ hipError_t pfk_measure_fast(hipStream_t st, const double* pose, int P, const uin
 #define PF_ORDER_BUCKETS 32768
 struct PfOrderParams {
     double qa, qx, qy;   // cells per radian of yaw / per voxel of x / per voxel of y
-    int32_t mode;        // 0: lexicographic yaw,x,y (6/4/5 bits)  1: Morton
+    int32_t mode;        // 0: lexicographic yaw,x,y (6/4/5 bits)  1: Morton  2: yaw-major 8/2/2 bits
     int32_t bits;        // Morton: bits per axis, 4 (4096 buckets) or 5 (32768 buckets)
 };
 #ifdef __HIPCC__
@@ -76,6 +84,7 @@ __device__ inline int order_key(const double* __restrict__ pose, int n, int i, P
     const int x = (int)floor(pose[6 * (size_t)n + i] * op.qx);
     const int y = (int)floor(pose[7 * (size_t)n + i] * op.qy);
     if (op.mode == 0) return ((a & 63) << 9) | ((x & 15) << 5) | (y & 31);
+    if (op.mode == 2) return ((a & 255) << 4) | ((x & 3) << 2) | (y & 3);      // yaw-major, 12 bits (k_measure_box)
     const int m = (1 << op.bits) - 1;                                          // Morton
     return (pf_spread3(a & m) << 2) | (pf_spread3(x & m) << 1) | pf_spread3(y & m);
 }
@@ -90,6 +99,16 @@ hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, i
 hipError_t pfk_measure_col(hipStream_t st, const double* sorted, int P, const uint8_t* shadow,
                            PfSwz sw, const PfColG* cg, const int group_ends[4], int n_chunks,
                            PfGridParams gp, double lmax, const int32_t* order, int2* partial);
+// K1 on LDS-staged boxes of the reference-order shared grid (pf_measure_box.hip). cl: the clusters,
+// ordered by blockIdx.y group; group_start: int [groups + 1] into cl. partial_l: int2 [groups][P] in
+// LANE order (pfk_reduce_scores_l un-permutes through order[]). kp, parts, lp, groups: pfk_box_plan.
+// Needs gz % 4 == 0 (rows are staged as aligned dwords).
+void pfk_box_plan(int P, int n_clusters, int* kp_out, int* parts_out, int* lp_out, int* groups_out);
+hipError_t pfk_measure_box(hipStream_t st, const double* sorted, int P, const uint8_t* maps, int gx, int gy, int gz,
+                           const PfColG* cg, const PfCluster* cl, const int* group_start, int kp, int parts, int lp,
+                           int groups, PfGridParams gp, double lmax, int2* partial_l);
+hipError_t pfk_reduce_scores_l(hipStream_t st, const int2* partial_l, int n_groups, int P, const int32_t* order,
+                               int2* scores, int32_t* bmin, int32_t* zero_a, int32_t* zero_b, int n_zero);
 hipError_t pfk_swz_build(hipStream_t st, const uint8_t* lin, uint8_t* shadow, PfSwz sw);
 // bmin: int32 [ceil(P/64)], the smallest sum_match of each 64-particle block
 // zero_a / zero_b: n_zero int32 each set to zero (the ordering's counters), n_zero may be 0

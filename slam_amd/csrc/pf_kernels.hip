@@ -451,7 +451,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     L.c = sorted[lane_id]; L.s = sorted[(size_t)P + lane_id];
     L.tx = sorted[2 * (size_t)P + lane_id]; L.ty = sorted[3 * (size_t)P + lane_id];
     L.tz = sorted[4 * (size_t)P + lane_id];
-    const int p = order[lane_id];
     L.ms = -L.s;
     const float cf = (float)L.c, sf = (float)L.s;
     L.rotA = v2f{cf, sf}; L.rotB = v2f{-sf, cf};
@@ -479,7 +478,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     col_phase<2>(cg, ends.y, ends.z, L, G, gp, shadow, sum, cnt);
     __builtin_amdgcn_s_setprio(0);
     col_phase<1>(cg, ends.z, ends.w, L, G, gp, shadow, sum, cnt);
-    partial[(size_t)blockIdx.y * P + p] = make_int2(sum, cnt);
+    // in lane order (coalesced); pfk_reduce_scores_l sends the sums to the particles through order[]
+    partial[(size_t)blockIdx.y * P + lane_id] = make_int2(sum, cnt);
     if (trace && (threadIdx.x & 63) == 0) {          // development aid: per-wave timeline
         const size_t w = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
         trace[4 * w + 0] = t_start; trace[4 * w + 1] = t_loop; trace[4 * w + 2] = wall_clock64();

@@ -191,3 +191,32 @@ def test_previous_best_survives_a_step_without_positive_weights(P):
         assert np.array_equal(slots, sa) and best == ob and best != prev
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("P,spread", [(3000, 1.0), (2500, 12.0), (5000, 0.2)])
+def test_lds_box_measure_kernel_matches_oracle(P, spread, monkeypatch):
+    """k_measure_box (SLAM_PF_K1=box: gathers from LDS-staged boxes of the grid): scores and voxel
+    indices equal the oracle's on a tight cloud, on a cloud spread so wide that boxes overflow LDS,
+    and with particles pushed to the grid's edge (lanes off an axis: the reference's flat-only
+    bounds test, S3P:882)."""
+    monkeypatch.setenv("SLAM_PF_K1", "box")
+    dims = (128, 128, 64)
+    sc = synth.scene(dims, P, 1500, seed=7)
+    rng = np.random.default_rng(P)
+    tp = sc["true_pose"]
+    x = tp[0] + rng.normal(0, 0.03 * spread, P); y = tp[1] + rng.normal(0, 0.03 * spread, P)
+    z = tp[2] + rng.normal(0, 0.015 * spread, P); yaw = tp[3] + rng.normal(0, 0.02 * spread, P)
+    x[:40] = rng.uniform(-0.3, 0.4, 40); y[40:80] = dims[1] * 0.05 + rng.uniform(-0.4, 0.3, 40)   # at the edges
+    z[80:100] = rng.uniform(-0.5, 0.2, 20)
+    z[100] = 1.475; z[101] = 0.525                                                             # z/res = k + 0.5: ambiguous shift
+    bx, by, bz, bv = sc["beams"]
+    h = capi.Handle(capi.default_config(n_particles=P, map_mode=capi.PF_MAP_SHARED, grid_x=dims[0], grid_y=dims[1],
+                                        grid_z=dims[2], local_x=0, local_y=0, local_z=0, max_beams=len(bx)))
+    try:
+        h.write_map(0, sc["grid"]); h.predict(x, y, z, yaw); h.set_beams(bx, by, bz, bv)
+        h.measure(0)
+        s, c = h.get_scores()
+        so, co = O.measure(O.ref_grid(*dims), x, y, z, yaw, sc["grid"].reshape(-1), 0, bx, by, bz, bv, 0)
+        assert np.array_equal(s, so) and np.array_equal(c, co)
+    finally:
+        h.close()

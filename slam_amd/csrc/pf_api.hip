@@ -14,12 +14,107 @@
 #include <string>
 #include <algorithm>
 #include <vector>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 namespace {
 
 std::string g_create_error;
 
 struct EventPair { hipEvent_t a, b; };
+
+// Pinned host staging for an upload the caller repeats every step: two slots, an event behind each
+// slot's copies. A call fills the slot whose copies of two calls ago have finished (normally long
+// ago) and never waits for the stream itself, so the host can prepare step i+1 while step i runs.
+struct Stage {
+    char* host[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    size_t cap = 0;
+    int flip = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        for (int k = 0; k < 2; ++k) {
+            if (ev[k]) { hipError_t e = hipEventSynchronize(ev[k]); if (e != hipSuccess) return e; }
+            if (host[k]) (void)hipHostFree(host[k]);
+            host[k] = nullptr;
+            hipError_t e = hipHostMalloc((void**)&host[k], bytes, hipHostMallocDefault);
+            if (e != hipSuccess) { cap = 0; return e; }
+            if (!ev[k]) { e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming); if (e != hipSuccess) return e; }
+        }
+        cap = bytes;
+        return hipSuccess;
+    }
+    // the slot to fill now (its earlier copies have left it)
+    hipError_t acquire(size_t bytes, char** out) {
+        hipError_t e = reserve(bytes);
+        if (e != hipSuccess) return e;
+        flip ^= 1;
+        e = hipEventSynchronize(ev[flip]);
+        *out = host[flip];
+        return e;
+    }
+    hipError_t commit(hipStream_t st) { return hipEventRecord(ev[flip], st); }
+    void release() {
+        for (int k = 0; k < 2; ++k) {
+            if (host[k]) (void)hipHostFree(host[k]);
+            if (ev[k]) (void)hipEventDestroy(ev[k]);
+            host[k] = nullptr; ev[k] = nullptr;
+        }
+        cap = 0;
+    }
+};
+
+// A few persistent host threads for the caller-side loops that stay on the CPU by design: the
+// per-particle cos/sin of pf_predict come from the host libm (S3P:860; the device's differ in the
+// last place for some arguments), the same function on every element whoever calls it.
+class HostPool {
+public:
+    explicit HostPool(int n) {
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { run(i); });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    int size() const { return (int)workers_.size(); }
+    // fn(part, parts) on every worker and on the caller (part == parts - 1); returns when all are done
+    void run_all(const std::function<void(int, int)>& fn) {
+        const int parts = size() + 1;
+        { std::lock_guard<std::mutex> lk(mu_); fn_ = &fn; pending_ = size(); ++gen_; }
+        cv_.notify_all();
+        fn(parts - 1, parts);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void run(int i) {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int, int)>* fn;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_;
+            }
+            (*fn)(i, size() + 1);
+            { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_.notify_one(); }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int, int)>* fn_ = nullptr;
+    unsigned long long gen_ = 0;
+    int pending_ = 0;
+    bool stop_ = false;
+};
 
 }  // namespace
 
@@ -52,6 +147,9 @@ struct pf_handle {
     PfSwz swz{};
     double* sorted = nullptr;          // [5][P] pose rows in lane order (written with order[])
     int8_t* local = nullptr;           // local int8 map
+    char* beam_blk = nullptr;          // one allocation behind the seven beam-list pointers below: pf_set_beams
+                                       // packs them into one pinned block and uploads it with ONE copy
+    size_t beam_blk_bytes = 0;
     PfBeam* beams = nullptr;           // [max_beams] every beam (fuse path, voxel indices)
     PfBeam* beams_occ = nullptr;       // [max_beams] occupied beams only (fast measure path)
     PfBeamF* beams_occ_f = nullptr;    // [max_beams] the same in fp32
@@ -122,6 +220,8 @@ struct pf_handle {
     double* wpts = nullptr;            // [max_points][3]
     int32_t* ray_idx = nullptr;        // [max_points]
     // host staging
+    Stage st_pose, st_beams, st_weights, st_scan;   // pinned, double-buffered (pf_predict, pf_set_beams, ...)
+    std::unique_ptr<HostPool> pool;                 // host threads for pf_predict's trig (created on first use)
     std::vector<double> h_pose;
     std::vector<PfBeam> h_beams, h_beams_occ;
     std::vector<PfBeamF> h_beams_occ_f;
@@ -285,27 +385,49 @@ hipError_t flush_update(pf_handle* h) {
 }
 hipError_t wait_map_writes(pf_handle* h) { return flush_update(h); }
 
-void upload_pose_rows(pf_handle* h, const double* x, const double* y, const double* z,
+void upload_pose_rows(pf_handle* h, double* hp, const double* x, const double* y, const double* z,
                       const double* yaw) {
     const int P = h->P;
-    double* hp = h->h_pose.data();
     const double res = h->cfg.resolution;
+    auto rows = [=](int lo, int hi) {
+        for (int i = lo; i < hi; ++i) {
+            hp[0 * (size_t)P + i] = x[i];
+            hp[1 * (size_t)P + i] = y[i];
+            hp[2 * (size_t)P + i] = z[i];
+            hp[3 * (size_t)P + i] = yaw[i];
+            hp[4 * (size_t)P + i] = cos(yaw[i]);          // S3P:860 via rot_matrix (host libm)
+            hp[5 * (size_t)P + i] = sin(yaw[i]);
+            hp[6 * (size_t)P + i] = x[i] * 1 / res;       // S3P:862-864: a division
+            hp[7 * (size_t)P + i] = y[i] * 1 / res;
+            hp[8 * (size_t)P + i] = z[i] * 1 / res;
+        }
+    };
     double ysum = 0;
     for (int i = 0; i < P; ++i) ysum += yaw[i];
     h->yaw_hint = ysum / P;
-    for (int i = 0; i < P; ++i) {
-        hp[0 * (size_t)P + i] = x[i];
-        hp[1 * (size_t)P + i] = y[i];
-        hp[2 * (size_t)P + i] = z[i];
-        hp[3 * (size_t)P + i] = yaw[i];
-        hp[4 * (size_t)P + i] = cos(yaw[i]);          // S3P:860 via rot_matrix (host libm)
-        hp[5 * (size_t)P + i] = sin(yaw[i]);
-        hp[6 * (size_t)P + i] = x[i] * 1 / res;       // S3P:862-864: a division
-        hp[7 * (size_t)P + i] = y[i] * 1 / res;
-        hp[8 * (size_t)P + i] = z[i] * 1 / res;
+    // the trig is ~30 ns per particle on one core: split it over a few host threads from a few
+    // thousand particles on (the same libm call per element, so the same bits)
+    if (P >= 4096) {
+        if (!h->pool) {
+            int n = (int)std::thread::hardware_concurrency();
+            if (const char* e = getenv("OMP_NUM_THREADS")) { const int v = atoi(e); if (v > 0) n = v; }
+            n = n < 2 ? 0 : (n > 16 ? 16 : n) - 1;
+            if (const char* e = getenv("SLAM_PF_HOST_THREADS")) n = atoi(e) > 0 ? atoi(e) - 1 : 0;
+            h->pool.reset(new HostPool(n));
+        }
+        if (h->pool->size() > 0) {
+            h->pool->run_all([&](int part, int parts) {
+                const long long per = ((long long)P + parts - 1) / parts;
+                const int lo = (int)std::min<long long>(P, per * part), hi = (int)std::min<long long>(P, per * (part + 1));
+                rows(lo, hi);
+            });
+            return;
+        }
     }
+    rows(0, P);
 }
 
+bool box_eligible(const pf_handle* h);
 // Clusters of beams for k_measure_box: recursive median splits of the occupied beams along their
 // longest extent (in a frame turned by the cloud's mean yaw, so that wall pieces are thin boxes of
 // the grid) until the box a cluster needs -- its extent plus the margin a particle cloud typically
@@ -317,7 +439,7 @@ void upload_pose_rows(pf_handle* h, const double* x, const double* y, const doub
 void build_clusters(pf_handle* h, int n_occ) {
     h->box_groups = 0;
     h->h_colc.clear(); h->h_clusters.clear(); h->h_group_start.clear();
-    if (n_occ == 0 || h->cfg.map_mode != PF_MAP_SHARED || h->cfg.grid_z % 4 != 0) return;
+    if (n_occ == 0 || !box_eligible(h)) return;
     double vol = 20000, mx = 12, my = 12, mz = 6;
     if (const char* e = getenv("SLAM_PF_BOX")) (void)sscanf(e, "%lf,%lf,%lf,%lf", &vol, &mx, &my, &mz);
     const double c0 = cos(h->yaw_hint), s0 = sin(h->yaw_hint);
@@ -423,7 +545,7 @@ void pf_destroy(pf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->bmin_all, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beams, h->beams_occ, h->beams_occ_f, h->beams_col, h->beams_colc, h->clusters, h->group_start,
+    void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->bmin_all, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beam_blk,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
                     h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -435,6 +557,7 @@ void pf_destroy(pf_handle* h) {
     for (hipEvent_t e : h->rs_event) if (e) (void)hipEventDestroy(e);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->h_u) (void)hipHostFree(h->h_u);
+    for (Stage* s : {&h->st_pose, &h->st_beams, &h->st_weights, &h->st_scan}) s->release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -536,13 +659,14 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     }
     if (h->local_elements)
         CREATE_TRY(dalloc(&h->local, (size_t)round_up((unsigned long long)h->local_elements, 256)));
-    CREATE_TRY(dalloc(&h->beams, (size_t)c.max_beams));
-    CREATE_TRY(dalloc(&h->beams_occ, (size_t)c.max_beams + PF_BEAM_GROUP));
-    CREATE_TRY(dalloc(&h->beams_occ_f, (size_t)c.max_beams + PF_BEAM_GROUP));
-    CREATE_TRY(dalloc(&h->beams_col, (size_t)c.max_beams + 1));
-    CREATE_TRY(dalloc(&h->beams_colc, (size_t)c.max_beams + 1));
-    CREATE_TRY(dalloc(&h->clusters, (size_t)c.max_beams + 1));
-    CREATE_TRY(dalloc(&h->group_start, (size_t)257));
+    {
+        const size_t mb = (size_t)c.max_beams;
+        h->beam_blk_bytes = 64 * 8 + sizeof(PfBeam) * mb + sizeof(PfColG) * (mb + 1) + sizeof(PfBeam) * (mb + PF_BEAM_GROUP) +
+                            sizeof(PfBeamF) * (mb + PF_BEAM_GROUP) + sizeof(PfColG) * (mb + 1) + sizeof(PfCluster) * (mb + 1) +
+                            sizeof(int) * 257;
+        CREATE_TRY(hipMalloc((void**)&h->beam_blk, h->beam_blk_bytes));
+        h->beams = (PfBeam*)h->beam_blk;       // (real offsets are set by every pf_set_beams)
+    }
     if (const char* e = getenv("SLAM_PF_K1")) h->k1_mode = !strcmp(e, "col") ? 1 : !strcmp(e, "box") ? 2 : 0;
     if (const char* e = getenv("SLAM_PF_TWO_GATHERS")) h->group_gathers = atoi(e) == 0;
     if (const char* e = getenv("SLAM_PF_CHUNKS")) h->tune_chunks = atoi(e);
@@ -598,7 +722,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     // S3P:47-51 initial state, S3P:71-77 prior
     {
         std::vector<double> x(P, 7.5), y(P, 7.5), z(P, 1.5), yaw(P, 0.0), w(Pg, 1.0 / (double)Pg);
-        upload_pose_rows(h, x.data(), y.data(), z.data(), yaw.data());
+        upload_pose_rows(h, h->h_pose.data(), x.data(), y.data(), z.data(), yaw.data());
         CREATE_TRY(hipMemcpyAsync(h->pose, h->h_pose.data(), sizeof(double) * PF_POSE_ROWS * P,
                                   hipMemcpyHostToDevice, h->stream));
         CREATE_TRY(hipMemcpyAsync(h->w, w.data(), sizeof(double) * Pg, hipMemcpyHostToDevice, h->stream));
@@ -621,11 +745,13 @@ int pf_predict(pf_handle* h, const double* x, const double* y, const double* z, 
         if (!(fabs(x[i]) < lim && fabs(y[i]) < lim && fabs(z[i]) < lim) || !isfinite(yaw[i]))
             return fail(h, PF_ERR_ARG, "pf_predict: particle %d pose not finite or |pos/res| >= 2^24", i);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));             // staging buffer reuse
     h->pose_src = nullptr;
-    upload_pose_rows(h, x, y, z, yaw);
-    HIP_TRY(h, hipMemcpyAsync(h->pose, h->h_pose.data(), sizeof(double) * PF_POSE_ROWS * h->P,
-                              hipMemcpyHostToDevice, h->stream));
+    const size_t nb = sizeof(double) * PF_POSE_ROWS * (size_t)h->P;
+    char* slot = nullptr;
+    HIP_TRY(h, h->st_pose.acquire(nb, &slot));               // pinned, double-buffered: no wait for the stream
+    upload_pose_rows(h, (double*)slot, x, y, z, yaw);
+    HIP_TRY(h, hipMemcpyAsync(h->pose, slot, nb, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, h->st_pose.commit(h->stream));
     HIP_TRY(h, drop_counted_keys(h));
     h->order_dirty = true;
     h->poses_gathered = false;
@@ -668,8 +794,11 @@ int pf_set_weights(pf_handle* h, const double* w) {
     if (!h) return PF_ERR_ARG;
     NEED(h, w, "null weights");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    HIP_TRY(h, hipMemcpyAsync(h->w, w, sizeof(double) * (size_t)h->Pg, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    char* slot = nullptr;
+    HIP_TRY(h, h->st_weights.acquire(sizeof(double) * (size_t)h->Pg, &slot));
+    memcpy(slot, w, sizeof(double) * (size_t)h->Pg);
+    HIP_TRY(h, hipMemcpyAsync(h->w, slot, sizeof(double) * (size_t)h->Pg, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, h->st_weights.commit(h->stream));
     h->weights_given = true;
     h->weighted = false;               // a CDF of older weights is stale now
     return PF_OK;
@@ -768,9 +897,6 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         }
     }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (n)
-        HIP_TRY(h, hipMemcpyAsync(h->beams, h->h_beams.data(), sizeof(PfBeam) * (size_t)n,
-                                  hipMemcpyHostToDevice, h->stream));
     // pad the occupied lists to a multiple of PF_BEAM_GROUP with beams no pose can bring into
     // the grid (|coordinate| ~ 2^22 voxels while |pos/res| < 2^24 ... the flat index stays far
     // outside [0, elements) for every validated pose: 2^22*gy*gz dominates)
@@ -813,24 +939,38 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
             h->col_ends[4 - n] = e;
         }
     }
-    if (h->n_cols)
-        HIP_TRY(h, hipMemcpyAsync(h->beams_col, h->h_cols.data(), sizeof(PfColG) * h->h_cols.size(),
-                                  hipMemcpyHostToDevice, h->stream));
-    if (h->box_groups > 0) {
-        HIP_TRY(h, hipMemcpyAsync(h->beams_colc, h->h_colc.data(), sizeof(PfColG) * h->h_colc.size(),
-                                  hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->clusters, h->h_clusters.data(), sizeof(PfCluster) * h->h_clusters.size(),
-                                  hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->group_start, h->h_group_start.data(), sizeof(int) * h->h_group_start.size(),
-                                  hipMemcpyHostToDevice, h->stream));
+    // everything goes through one pinned, double-buffered block: the call does not wait for the stream
+    {
+        struct Seg { void* dev; const void* src; size_t bytes; };
+        const Seg segs[] = {
+            {nullptr, h->h_beams.data(), sizeof(PfBeam) * (size_t)n},
+            {nullptr, h->h_cols.data(), sizeof(PfColG) * h->h_cols.size()},
+            {nullptr, h->h_beams_occ.data(), sizeof(PfBeam) * no},
+            {nullptr, h->h_beams_occ_f.data(), sizeof(PfBeamF) * no},
+            {nullptr, h->h_colc.data(), h->box_groups > 0 ? sizeof(PfColG) * h->h_colc.size() : 0},
+            {nullptr, h->h_clusters.data(), h->box_groups > 0 ? sizeof(PfCluster) * h->h_clusters.size() : 0},
+            {nullptr, h->h_group_start.data(), h->box_groups > 0 ? sizeof(int) * h->h_group_start.size() : 0},
+        };
+        size_t total = 64;
+        for (const Seg& sg : segs) total += (sg.bytes + 63) & ~(size_t)63;
+        if (total > h->beam_blk_bytes) return fail(h, PF_ERR_ARG, "pf_set_beams: beam lists beyond the handle's capacity");
+        char* slot = nullptr;
+        HIP_TRY(h, h->st_beams.acquire(total, &slot));
+        size_t off = 0;
+        char* dev_at[7];
+        int k = 0;
+        for (const Seg& sg : segs) {
+            dev_at[k++] = h->beam_blk + off;
+            if (!sg.bytes) continue;
+            memcpy(slot + off, sg.src, sg.bytes);
+            off += (sg.bytes + 63) & ~(size_t)63;
+        }
+        if (off) HIP_TRY(h, hipMemcpyAsync(h->beam_blk, slot, off, hipMemcpyHostToDevice, h->stream));
+        h->beams = (PfBeam*)dev_at[0]; h->beams_col = (PfColG*)dev_at[1]; h->beams_occ = (PfBeam*)dev_at[2];
+        h->beams_occ_f = (PfBeamF*)dev_at[3]; h->beams_colc = (PfColG*)dev_at[4]; h->clusters = (PfCluster*)dev_at[5];
+        h->group_start = (int*)dev_at[6];
+        HIP_TRY(h, h->st_beams.commit(h->stream));
     }
-    if (no) {
-        HIP_TRY(h, hipMemcpyAsync(h->beams_occ, h->h_beams_occ.data(), sizeof(PfBeam) * no,
-                                  hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->beams_occ_f, h->h_beams_occ_f.data(), sizeof(PfBeamF) * no,
-                                  hipMemcpyHostToDevice, h->stream));
-    }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->M = (int)n;
     h->M_occ = (int)no;
     h->M_occ_real = n_real_occ;
@@ -841,12 +981,14 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
 // K1 lane order: Morton key over (yaw, x/res, y/res) in cells of 1/200 rad and 1/3 voxel; 4 bits
 // per axis sort 64-lane waves finely enough up to 64k particles per handle, 5 bits beyond.
 // SLAM_PF_ORDER=qa,qx,qy,mode,bits overrides (development knob).
-static bool box_eligible(const pf_handle* h) {
+namespace {
+bool box_eligible(const pf_handle* h) {
     // opt-in (SLAM_PF_K1=box): measured slower than the gather-layout kernel at every BASELINE size so
     // far (the per-cluster barrier makes every wave wait for the one with the most
     // fp64-corrected columns, and the sparse bench scan stages 15 KB per nine beams)
     return h->cfg.map_mode == PF_MAP_SHARED && h->cfg.grid_z % 4 == 0 && !h->force_exact_measure && h->k1_mode == 2;
 }
+}  // namespace
 static PfOrderParams order_params(const pf_handle* h) {
     PfOrderParams op{200.0, 3.0, 3.0, 1, h->P <= 65536 ? 4 : 5};
     // k_measure_box wants its workgroups' particles close in yaw (the box of a cluster grows with
@@ -1177,11 +1319,18 @@ int pf_set_scan(pf_handle* h, const double* points, int64_t n_points, const int3
             return fail(h, PF_ERR_ARG, "pf_set_scan: ray_idx[%lld] outside [0, n_points)", (long long)r);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, wait_map_writes(h));
-    if (n_points)
-        HIP_TRY(h, hipMemcpyAsync(h->points, points, sizeof(double) * 3 * (size_t)n_points, hipMemcpyHostToDevice, h->stream));
-    if (n_rays)
-        HIP_TRY(h, hipMemcpyAsync(h->ray_idx, ray_idx, sizeof(int32_t) * (size_t)n_rays, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t nb_p = sizeof(double) * 3 * (size_t)n_points, nb_r = sizeof(int32_t) * (size_t)n_rays;
+    char* slot = nullptr;
+    HIP_TRY(h, h->st_scan.acquire(nb_p + nb_r + 8, &slot));
+    if (n_points) {
+        memcpy(slot, points, nb_p);
+        HIP_TRY(h, hipMemcpyAsync(h->points, slot, nb_p, hipMemcpyHostToDevice, h->stream));
+    }
+    if (n_rays) {
+        memcpy(slot + nb_p, ray_idx, nb_r);
+        HIP_TRY(h, hipMemcpyAsync(h->ray_idx, slot + nb_p, nb_r, hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(h, h->st_scan.commit(h->stream));
     h->n_points = (int)n_points; h->n_rays = (int)n_rays;
     return PF_OK;
 }

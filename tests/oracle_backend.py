@@ -13,7 +13,8 @@ from oracle import binding as O
 
 
 class OracleHandle:
-    def __init__(self, P, Pg=None, offset=0, grid=None, per_particle=True, world=None, prior=50):
+    def __init__(self, P, Pg=None, offset=0, grid=None, per_particle=True, world=None, prior=50, dist=None):
+        self.dist = dist          # torch.distributed of a sharded run: carries the map slabs between ranks
         self.P = P
         self.Pg = Pg if Pg is not None else P
         self.offset = offset
@@ -97,6 +98,8 @@ class OracleHandle:
                 if a != self.offset + i:
                     new[:, i] = allp[a // self.P, :, a % self.P]
             self.pose[...] = new      # in place: the buffer address is fixed, like the device one
+            if self.per_particle:
+                self._migrate_maps(sa)
         else:
             rec = np.ascontiguousarray(self.pose.T)
             O.permute(sa, rec)
@@ -107,6 +110,33 @@ class OracleHandle:
         O.permute(sa, lw)
         self.logw = lw
         return sa, best, nohit, 0
+
+    def _migrate_maps(self, sa):
+        """S3P:810 across ranks, the way pf_resample does it inside the library: slabs whose ancestor is
+        local are copied, the others travel by the transfer lists of pfh_migration_plan (here over
+        torch.distributed send/recv instead of RCCL: receives posted first, one tag per transfer)."""
+        from slam_amd import capi
+        rank = self.offset // self.P
+        old = self.maps.copy()
+        for i in range(self.P):
+            a = int(sa[self.offset + i])
+            if a != self.offset + i and self.offset <= a < self.offset + self.P:
+                self.maps[i] = old[a - self.offset]
+        total, sends, recvs = capi.migration_plan(sa, self.P, rank)
+        self.last_transfers = (total, len(sends), len(recvs))
+        if not sends and not recvs:
+            return
+        bufs, work = [], []
+        for dst, peer, seq in recvs:
+            t = torch.empty(self.elements, dtype=torch.uint8)
+            bufs.append((dst, t))
+            work.append(self.dist.irecv(t, src=peer, tag=int(seq)))
+        for src, peer, seq in sends:
+            work.append(self.dist.isend(torch.from_numpy(old[src].copy()), dst=peer, tag=int(seq)))
+        for wk in work:
+            wk.wait()
+        for dst, t in bufs:
+            self.maps[dst] = t.numpy()
 
 
 class _Cfg:

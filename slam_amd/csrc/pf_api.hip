@@ -163,6 +163,14 @@ struct pf_handle {
     std::vector<PfCluster> h_clusters;
     std::vector<int> h_group_start;
     int box_kp = 1, box_parts = 1, box_lp = 1, box_groups = 0;   // pfk_box_plan; groups 0 = no plan
+    // k_measure_fuse_cols (per-particle maps): the full beam list as columns and their dense values
+    PfFCol* fcols = nullptr;
+    uint8_t* fvals = nullptr;
+    std::vector<PfFCol> h_fcols;
+    uint8_t* focc = nullptr;
+    std::vector<uint8_t> h_fvals, h_focc;
+    PfFColBounds fbounds{};
+    int n_fcols = 0;                   // 0: the beam list does not qualify, k_measure_fuse_wave takes the step
     int partial_rows = 1;              // rows of `partial` (chunks of the col kernels / groups of the box kernel)
     int k1_mode = 0;                   // SLAM_PF_K1: 0 auto, 1 col (gather layout), 2 box (LDS) whenever possible
     double yaw_hint = 0.0;             // mean yaw of the last host-side predict: aligns the clusters with the grid
@@ -436,6 +444,58 @@ bool box_eligible(const pf_handle* h);
 // to the blockIdx.y groups, largest first onto the least loaded one. SLAM_PF_BOX=volume,mx,my,mz
 // overrides the budget (cells) and the margins (development knob). Any clustering gives the same
 // results; it only decides how much a workgroup stages per evaluation.
+// The full beam list as local columns for k_measure_fuse_cols: maximal runs that share (lx, ly) and
+// ascend strictly in lz (the order S3P:868-877 produces), cut at PF_FCOL_MAXZ cells. Left empty when the
+// kernel's conditions do not hold: the step then runs beam by beam (k_measure_fuse_wave).
+void build_fuse_columns(pf_handle* h) {
+    h->h_fcols.clear(); h->h_fvals.clear(); h->h_focc.clear(); h->n_fcols = 0;
+    static const bool off = getenv("SLAM_PF_FUSE_COLS") && atoi(getenv("SLAM_PF_FUSE_COLS")) == 0;
+    if (off || h->cfg.map_mode != PF_MAP_PER_PARTICLE || h->cfg.grid_z % 16 != 0 || h->slab % 16 != 0 ||
+        h->elements >= 2147483648ll || h->h_beams.empty())
+        return;
+    const std::vector<PfBeam>& B = h->h_beams;
+    const int n = (int)B.size();
+    std::vector<PfFCol>& C = h->h_fcols;
+    std::vector<int> first;                       // first beam of each column
+    PfFColBounds bd{(float)B[0].lx, (float)B[0].lx, (float)B[0].ly, (float)B[0].ly, (int32_t)B[0].lz, (int32_t)B[0].lz};
+    for (int j = 0; j < n;) {
+        if (B[(size_t)j].v == 0) { C.clear(); return; }        // 0 means "no beam" in the values
+        PfFCol c{};
+        c.lx = (float)B[(size_t)j].lx; c.ly = (float)B[(size_t)j].ly;        // exact: |offset| <= 2^20
+        c.z0 = (int32_t)B[(size_t)j].lz;
+        int k = j + 1;
+        while (k < n && B[(size_t)k].lx == B[(size_t)j].lx && B[(size_t)k].ly == B[(size_t)j].ly && B[(size_t)k].v != 0 &&
+               B[(size_t)k].lz > B[(size_t)k - 1].lz && (int32_t)B[(size_t)k].lz - c.z0 < PF_FCOL_MAXZ)
+            ++k;
+        c.n = (int32_t)B[(size_t)k - 1].lz - c.z0 + 1;
+        bd.lx0 = fminf(bd.lx0, c.lx); bd.lx1 = fmaxf(bd.lx1, c.lx); bd.ly0 = fminf(bd.ly0, c.ly); bd.ly1 = fmaxf(bd.ly1, c.ly);
+        bd.z0 = std::min(bd.z0, c.z0); bd.z1 = std::max(bd.z1, c.z0 + c.n - 1);
+        C.push_back(c); first.push_back(j);
+        j = k;
+    }
+    first.push_back(n);
+    // values and flag bytes, columns in list order (the kernel's election keeps the list's order per cell)
+    std::vector<uint8_t>&V = h->h_fvals, &O = h->h_focc;
+    V.assign(16, 0); O.assign(16, 0);
+    for (size_t i = 0; i < C.size(); ++i) {
+        PfFCol& c = C[i];
+        const int e = c.z0 & 15;
+        const size_t base = V.size();
+        c.voff = (int32_t)(base / 16);
+        V.resize(base + (((size_t)(e + c.n) + 15) & ~(size_t)15) + 16, 0);     // the run's units and the zero unit behind them
+        O.resize(V.size(), 0);
+        for (int q = first[i]; q < first[i + 1]; ++q) {
+            const size_t at = base + (size_t)(e + (int32_t)B[(size_t)q].lz - c.z0);
+            V[at] = (uint8_t)(int8_t)B[(size_t)q].v;
+            O[at] = 0xfe;
+            if (B[(size_t)q].v > h->cfg.occ_threshold) { O[at] = 0xff; ++c.cnt; }
+        }
+    }
+    V.resize(V.size() + 48, 0); O.resize(V.size(), 0);          // the last column's loads run up to 31 bytes past its zero unit
+    h->fbounds = bd;
+    h->n_fcols = (int)C.size();
+}
+
 void build_clusters(pf_handle* h, int n_occ) {
     h->box_groups = 0;
     h->h_colc.clear(); h->h_clusters.clear(); h->h_group_start.clear();
@@ -664,6 +724,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
         h->beam_blk_bytes = 64 * 8 + sizeof(PfBeam) * mb + sizeof(PfColG) * (mb + 1) + sizeof(PfBeam) * (mb + PF_BEAM_GROUP) +
                             sizeof(PfBeamF) * (mb + PF_BEAM_GROUP) + sizeof(PfColG) * (mb + 1) + sizeof(PfCluster) * (mb + 1) +
                             sizeof(int) * 257;
+        if (c.map_mode == PF_MAP_PER_PARTICLE)      // worst case, every beam a column of its own: 32 B + two units
+            h->beam_blk_bytes += 64 * 3 + sizeof(PfFCol) * mb + 2 * (32 * mb + 64);
         CREATE_TRY(hipMalloc((void**)&h->beam_blk, h->beam_blk_bytes));
         h->beams = (PfBeam*)h->beam_blk;       // (real offsets are set by every pf_set_beams)
     }
@@ -925,6 +987,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         h->h_cols.push_back(g);
     }
     build_clusters(h, n_real_occ);
+    build_fuse_columns(h);
     // ... and inside a phase by range: how far the lanes of a wave spread over cache lines grows
     // with the beam's range, so neighbours in this order cost about the same and go to different chunks
     std::stable_sort(h->h_cols.begin(), h->h_cols.end(), [](const PfColG& a, const PfColG& b) {
@@ -950,6 +1013,9 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
             {nullptr, h->h_colc.data(), h->box_groups > 0 ? sizeof(PfColG) * h->h_colc.size() : 0},
             {nullptr, h->h_clusters.data(), h->box_groups > 0 ? sizeof(PfCluster) * h->h_clusters.size() : 0},
             {nullptr, h->h_group_start.data(), h->box_groups > 0 ? sizeof(int) * h->h_group_start.size() : 0},
+            {nullptr, h->h_fcols.data(), h->n_fcols > 0 ? sizeof(PfFCol) * h->h_fcols.size() : 0},
+            {nullptr, h->h_fvals.data(), h->n_fcols > 0 ? h->h_fvals.size() : 0},
+            {nullptr, h->h_focc.data(), h->n_fcols > 0 ? h->h_focc.size() : 0},
         };
         size_t total = 64;
         for (const Seg& sg : segs) total += (sg.bytes + 63) & ~(size_t)63;
@@ -957,7 +1023,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         char* slot = nullptr;
         HIP_TRY(h, h->st_beams.acquire(total, &slot));
         size_t off = 0;
-        char* dev_at[7];
+        char* dev_at[10];
         int k = 0;
         for (const Seg& sg : segs) {
             dev_at[k++] = h->beam_blk + off;
@@ -969,6 +1035,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         h->beams = (PfBeam*)dev_at[0]; h->beams_col = (PfColG*)dev_at[1]; h->beams_occ = (PfBeam*)dev_at[2];
         h->beams_occ_f = (PfBeamF*)dev_at[3]; h->beams_colc = (PfColG*)dev_at[4]; h->clusters = (PfCluster*)dev_at[5];
         h->group_start = (int*)dev_at[6];
+        h->fcols = (PfFCol*)dev_at[7]; h->fvals = (uint8_t*)dev_at[8]; h->focc = (uint8_t*)dev_at[9];
         HIP_TRY(h, h->st_beams.commit(h->stream));
     }
     h->M = (int)n;
@@ -1062,6 +1129,10 @@ int pf_measure(pf_handle* h, int add_points) {
             HIP_TRY(h, pfk_measure_col(h->stream, h->sorted, h->P, h->shadow, h->swz, h->beams_col, h->col_ends,
                                        chunks, grid_params(h), h->lmax_occ, h->order, h->partial));
         }
+        else if (fuse && h->n_fcols > 0)
+            HIP_TRY(h, pfk_measure_fuse_cols(h->stream, h->pose, h->P, h->maps, h->slab, h->beams, h->M, h->fcols, h->n_fcols,
+                                             h->fvals, h->focc, h->fbounds, h->cfg.grid_x, h->cfg.grid_y, h->cfg.grid_z,
+                                             grid_params(h), h->partial));
         else if (fuse)
             HIP_TRY(h, pfk_measure(h->stream, h->pose, h->P, h->maps, h->slab, h->beams, h->M, 1, bpc,
                                    grid_params(h), true, h->partial));

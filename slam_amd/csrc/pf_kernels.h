@@ -41,6 +41,22 @@ struct __attribute__((aligned(32))) PfCluster {
     int32_t lz0, lz1;
 };
 
+// One local column of the FULL beam list for k_measure_fuse_cols (32 B): a run of beams that share
+// (lx, ly) and ascend strictly in lz from z0 over n <= PF_FCOL_MAXZ cells (cells of the run without a
+// beam hold the value 0); cnt of them count as occupied (S3P:886). Its int8 values lie in the values
+// array in 16-byte units aligned to the local z grid: unit voff covers lz in [floor16(z0), +16); a zero
+// unit lies in front of and behind every column.
+#define PF_FCOL_MAXZ 65
+struct __attribute__((aligned(32))) PfFCol {
+    float lx, ly;
+    int32_t z0, n, voff, cnt, pad[2];
+};
+// bounds of the whole beam list (z1 inclusive)
+struct PfFColBounds {
+    float lx0, lx1, ly0, ly1;
+    int32_t z0, z1;
+};
+
 // Pose block: double [PF_POSE_ROWS][n] = x, y, z, yaw, cos, sin, x/res, y/res, z/res.
 #define PF_POSE_ROWS 9
 
@@ -56,6 +72,12 @@ struct PfGridParams {
 hipError_t pfk_measure(hipStream_t st, const double* pose, int P, uint8_t* maps,
                        unsigned long long map_stride, const PfBeam* beams, int M, int n_chunks,
                        int beams_per_chunk, PfGridParams gp, bool fuse, int2* partial);
+// K1+K2 column-wise on per-particle maps (pf_fuse_cols.hip). Needs gz % 16 == 0, map_stride % 16 == 0,
+// elements < 2^31, every beam value non-zero. occ: the values' layout, 0xfe a beam, 0xff an occupied beam.
+// partial: int2 [P].
+hipError_t pfk_measure_fuse_cols(hipStream_t st, const double* pose, int P, uint8_t* maps, unsigned long long map_stride,
+                                 const PfBeam* beams, int M, const PfFCol* cols, int n_cols, const void* vals,
+                                 const void* occ, PfFColBounds bd, int gx, int gy, int gz, PfGridParams gp, int2* partial);
 // The occupied-beam lists are padded to a multiple of PF_BEAM_GROUP with out-of-bounds beams;
 // M and bpc passed to pfk_measure_fast are multiples of it.
 #define PF_BEAM_GROUP 4

@@ -167,8 +167,7 @@ struct pf_handle {
     PfFCol* fcols = nullptr;
     uint8_t* fvals = nullptr;
     std::vector<PfFCol> h_fcols;
-    uint8_t* focc = nullptr;
-    std::vector<uint8_t> h_fvals, h_focc;
+    std::vector<uint8_t> h_fvals;
     PfFColBounds fbounds{};
     int n_fcols = 0;                   // 0: the beam list does not qualify, k_measure_fuse_wave takes the step
     int partial_rows = 1;              // rows of `partial` (chunks of the col kernels / groups of the box kernel)
@@ -448,7 +447,7 @@ bool box_eligible(const pf_handle* h);
 // ascend strictly in lz (the order S3P:868-877 produces), cut at PF_FCOL_MAXZ cells. Left empty when the
 // kernel's conditions do not hold: the step then runs beam by beam (k_measure_fuse_wave).
 void build_fuse_columns(pf_handle* h) {
-    h->h_fcols.clear(); h->h_fvals.clear(); h->h_focc.clear(); h->n_fcols = 0;
+    h->h_fcols.clear(); h->h_fvals.clear(); h->n_fcols = 0;
     static const bool off = getenv("SLAM_PF_FUSE_COLS") && atoi(getenv("SLAM_PF_FUSE_COLS")) == 0;
     if (off || h->cfg.map_mode != PF_MAP_PER_PARTICLE || h->cfg.grid_z % 16 != 0 || h->slab % 16 != 0 ||
         h->elements >= 2147483648ll || h->h_beams.empty())
@@ -475,23 +474,21 @@ void build_fuse_columns(pf_handle* h) {
     }
     first.push_back(n);
     // values and flag bytes, columns in list order (the kernel's election keeps the list's order per cell)
-    std::vector<uint8_t>&V = h->h_fvals, &O = h->h_focc;
-    V.assign(16, 0); O.assign(16, 0);
+    std::vector<uint8_t>& V = h->h_fvals;
+    V.assign(16, 0);
     for (size_t i = 0; i < C.size(); ++i) {
         PfFCol& c = C[i];
         const int e = c.z0 & 15;
         const size_t base = V.size();
         c.voff = (int32_t)(base / 16);
         V.resize(base + (((size_t)(e + c.n) + 15) & ~(size_t)15) + 16, 0);     // the run's units and the zero unit behind them
-        O.resize(V.size(), 0);
         for (int q = first[i]; q < first[i + 1]; ++q) {
             const size_t at = base + (size_t)(e + (int32_t)B[(size_t)q].lz - c.z0);
             V[at] = (uint8_t)(int8_t)B[(size_t)q].v;
-            O[at] = 0xfe;
-            if (B[(size_t)q].v > h->cfg.occ_threshold) { O[at] = 0xff; ++c.cnt; }
+            if (B[(size_t)q].v > h->cfg.occ_threshold) ++c.cnt;
         }
     }
-    V.resize(V.size() + 48, 0); O.resize(V.size(), 0);          // the last column's loads run up to 31 bytes past its zero unit
+    V.resize(V.size() + 48, 0);         // the last column's loads run up to 31 bytes past its zero unit
     h->fbounds = bd;
     h->n_fcols = (int)C.size();
 }
@@ -725,7 +722,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
                             sizeof(PfBeamF) * (mb + PF_BEAM_GROUP) + sizeof(PfColG) * (mb + 1) + sizeof(PfCluster) * (mb + 1) +
                             sizeof(int) * 257;
         if (c.map_mode == PF_MAP_PER_PARTICLE)      // worst case, every beam a column of its own: 32 B + two units
-            h->beam_blk_bytes += 64 * 3 + sizeof(PfFCol) * mb + 2 * (32 * mb + 64);
+            h->beam_blk_bytes += 64 * 2 + sizeof(PfFCol) * mb + 32 * mb + 64;
         CREATE_TRY(hipMalloc((void**)&h->beam_blk, h->beam_blk_bytes));
         h->beams = (PfBeam*)h->beam_blk;       // (real offsets are set by every pf_set_beams)
     }
@@ -1015,7 +1012,6 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
             {nullptr, h->h_group_start.data(), h->box_groups > 0 ? sizeof(int) * h->h_group_start.size() : 0},
             {nullptr, h->h_fcols.data(), h->n_fcols > 0 ? sizeof(PfFCol) * h->h_fcols.size() : 0},
             {nullptr, h->h_fvals.data(), h->n_fcols > 0 ? h->h_fvals.size() : 0},
-            {nullptr, h->h_focc.data(), h->n_fcols > 0 ? h->h_focc.size() : 0},
         };
         size_t total = 64;
         for (const Seg& sg : segs) total += (sg.bytes + 63) & ~(size_t)63;
@@ -1023,7 +1019,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         char* slot = nullptr;
         HIP_TRY(h, h->st_beams.acquire(total, &slot));
         size_t off = 0;
-        char* dev_at[10];
+        char* dev_at[9];
         int k = 0;
         for (const Seg& sg : segs) {
             dev_at[k++] = h->beam_blk + off;
@@ -1035,7 +1031,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         h->beams = (PfBeam*)dev_at[0]; h->beams_col = (PfColG*)dev_at[1]; h->beams_occ = (PfBeam*)dev_at[2];
         h->beams_occ_f = (PfBeamF*)dev_at[3]; h->beams_colc = (PfColG*)dev_at[4]; h->clusters = (PfCluster*)dev_at[5];
         h->group_start = (int*)dev_at[6];
-        h->fcols = (PfFCol*)dev_at[7]; h->fvals = (uint8_t*)dev_at[8]; h->focc = (uint8_t*)dev_at[9];
+        h->fcols = (PfFCol*)dev_at[7]; h->fvals = (uint8_t*)dev_at[8];
         HIP_TRY(h, h->st_beams.commit(h->stream));
     }
     h->M = (int)n;
@@ -1131,7 +1127,7 @@ int pf_measure(pf_handle* h, int add_points) {
         }
         else if (fuse && h->n_fcols > 0)
             HIP_TRY(h, pfk_measure_fuse_cols(h->stream, h->pose, h->P, h->maps, h->slab, h->beams, h->M, h->fcols, h->n_fcols,
-                                             h->fvals, h->focc, h->fbounds, h->cfg.grid_x, h->cfg.grid_y, h->cfg.grid_z,
+                                             h->fvals, h->fbounds, h->cfg.grid_x, h->cfg.grid_y, h->cfg.grid_z,
                                              grid_params(h), h->partial));
         else if (fuse)
             HIP_TRY(h, pfk_measure(h->stream, h->pose, h->P, h->maps, h->slab, h->beams, h->M, 1, bpc,

@@ -33,8 +33,7 @@
 // front of and behind every column. The map piece q of a column then needs the 16 value bytes that
 // start 16 (q + carry) - r bytes into the column's units, with r = (z shift of the particle) mod 16
 // the same for the whole wave and carry = 0/1 per column: dword loads plus v_alignbyte with a
-// wave-uniform shift. A second array of the same layout holds a flag byte per cell: 0 no beam, 0xfe a
-// beam, 0xff a beam that counts as occupied (S3P:886).
+// wave-uniform shift.
 #include "pf_kernels.h"
 #include "pf_device.h"
 #include <stdio.h>
@@ -45,6 +44,7 @@
 #define FC_LPC 5                              // lanes (16-byte pieces) per column in the piece phase
 #define FC_CPP (64 / FC_LPC)                  // columns per pass
 #define FC_PASSES 5
+#define FC_DEPTH 2                            // passes whose loads are in flight together
 #define FC_SLOTS (FC_CPP * FC_PASSES)         // columns a wave holds at a time (one per lane 0 .. FC_SLOTS-1)
 static_assert(PF_FCOL_MAXZ + 15 <= 16 * FC_LPC, "a column spans at most FC_LPC 16-byte pieces");
 static_assert(FC_SLOTS <= 64, "one column slot per lane");
@@ -114,25 +114,32 @@ __device__ __forceinline__ void fuse_beam_range(int j0, int j1, const PfBeam* __
     }
 }
 
-// four map cells, the four beam values that meet them and their flag bytes (0: no beam on this cell,
-// 0xfe: a beam, 0xff: an occupied beam), S3P:886-904 on 16-bit pairs: cells 0, 2 and cells 1, 3
-__device__ __forceinline__ unsigned fuse_dword(unsigned cells, unsigned vals, unsigned flg, s2 lo2, s2 hi2, int& sum) {
-    sum = (int)__builtin_amdgcn_udot4(cells, flg & 0x01010101u, (unsigned)sum, false);          // S3P:886-889
+// four map cells and the four beam values that meet them (0: no beam on this cell), S3P:886-904 on
+// 16-bit pairs: cells 0, 2 and cells 1, 3. acc gathers cell * [value > occ_threshold] per 16-bit half
+// (at most 2 * 4 * 255 per 16-byte piece, read out by the caller before it can overflow).
+__device__ __forceinline__ unsigned fuse_dword(unsigned cells, unsigned vals, s2 lo2, s2 hi2, s2 thr2, us2& acc) {
     const s2 c02 = __builtin_bit_cast(s2, cells & 0x00ff00ffu), c13 = __builtin_bit_cast(s2, (cells >> 8) & 0x00ff00ffu);
     const s2 v02 = __builtin_bit_cast(s2, __builtin_bit_cast(us2, vals) << (us2)(8)) >> (s2)(8);
     const s2 v13 = __builtin_bit_cast(s2, vals) >> (s2)(8);
+    // S3P:886-889: [v > threshold] = clamp(v - threshold, 0, 1); the local map holds no zero beams, a cell
+    // without a beam (value 0) must not count whatever the threshold
+    const s2 zero = (s2)((short)0);
+    const s2 z02 = __builtin_bit_cast(s2, __builtin_elementwise_min(__builtin_bit_cast(us2, v02), (us2)((unsigned short)1)));
+    const s2 z13 = __builtin_bit_cast(s2, __builtin_elementwise_min(__builtin_bit_cast(us2, v13), (us2)((unsigned short)1)));
+    const s2 o02 = __builtin_elementwise_min(__builtin_elementwise_max(v02 - thr2, zero), z02);
+    const s2 o13 = __builtin_elementwise_min(__builtin_elementwise_max(v13 - thr2, zero), z13);
+    acc += __builtin_bit_cast(us2, c02 * o02) + __builtin_bit_cast(us2, c13 * o13);
     const s2 n02 = __builtin_elementwise_min(__builtin_elementwise_max(c02 + v02, lo2), hi2);  // S3P:895-904
     const s2 n13 = __builtin_elementwise_min(__builtin_elementwise_max(c13 + v13, lo2), hi2);
-    const unsigned nv = __builtin_bit_cast(unsigned, n02) | (__builtin_bit_cast(unsigned, n13) << 8);
     // S3P:870: a zero cell of the local map is no beam, the map cell stays as it is (whatever it holds)
-    const unsigned beam = ((flg >> 1) & 0x01010101u) | flg;
-    return (nv & beam) | (cells & ~beam);
+    const s2 r02 = c02 + z02 * (n02 - c02), r13 = c13 + z13 * (n13 - c13);
+    return __builtin_bit_cast(unsigned, r02) | (__builtin_bit_cast(unsigned, r13) << 8);
 }
 
 __global__ __launch_bounds__(256) void k_measure_fuse_cols(
         const double* __restrict__ pose, int P, uint8_t* maps, unsigned long long map_stride,
         const PfBeam* __restrict__ beams, int M, const PfFCol* __restrict__ cols, int n_cols,
-        const unsigned char* __restrict__ vals, const unsigned char* __restrict__ occ, PfFColBounds bd,
+        const unsigned char* __restrict__ vals, PfFColBounds bd,
         int gx, int gy, int gz, PfGridParams gp, int2* __restrict__ partial, unsigned* stats) {
     __shared__ unsigned keys[4][FC_TBL];
     __shared__ unsigned minl[4][FC_TBL];
@@ -180,32 +187,28 @@ __global__ __launch_bounds__(256) void k_measure_fuse_cols(
         const unsigned r = (unsigned)zp & 15u;                                 // wave-uniform
         const unsigned bsh = (0u - r) & 3u;                                    // byte shift of the value windows
         const s2 lo2 = (s2)((short)gp.lo), hi2 = (s2)((short)gp.hi);
+        const s2 thr2 = (s2)((short)max(-200, min(200, gp.occ_threshold)));     // int8 values: any threshold beyond +-128 acts alike
         int next = 0;                                                           // wave-uniform: first column not yet taken
         bool pending = false;
         unsigned key = 0, seg0 = 0, s0 = 0, myci = 0, slot = 0;
         int nseg = 0;
-        while (true) {
-            if (next < n_cols) {                                                // free lanes take the next columns of the list
-                const unsigned long long freem = __ballot(!pending && lane < FC_SLOTS);
-                const int ci = next + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
-                if (!pending && lane < FC_SLOTS && ci < n_cols) {
-                    const PfFCol col = cols[ci];
-                    // S3P:745-747, 880 for the column (x and y do not depend on lz)
-                    const int X = (int)round((c * (double)col.lx + ms * (double)col.ly) + tx);
-                    const int Y = (int)round((s * (double)col.lx + c * (double)col.ly) + ty);
-                    key = (unsigned)X * (unsigned)gy + (unsigned)Y;
-                    const unsigned a0 = key * (unsigned)gz + (unsigned)(col.z0 + zp);   // first cell of the run (rows are 16-aligned)
-                    seg0 = a0 & ~15u;
-                    nseg = (int)(((a0 & 15u) + (unsigned)col.n + 15u) >> 4);
-                    const unsigned carry = (((unsigned)col.z0 & 15u) + r) >> 4;
-                    s0 = 16u * ((unsigned)col.voff + carry) - r;                        // byte offset of piece 0's values
-                    cnt += col.cnt;                                                     // S3P:888: every beam is in range here
-                    myci = (unsigned)ci;
-                    pending = true;
-                }
-                next = min(n_cols, next + (int)__popcll(freem));
-            }
-            if (!__any(pending)) break;
+        // S3P:745-747, 880 for a column (x and y do not depend on lz), its key, addresses and piece count
+        auto take = [&](const PfFCol& col, int ci) {
+            const int X = (int)round((c * (double)col.lx + ms * (double)col.ly) + tx);
+            const int Y = (int)round((s * (double)col.lx + c * (double)col.ly) + ty);
+            key = (unsigned)X * (unsigned)gy + (unsigned)Y;
+            const unsigned a0 = key * (unsigned)gz + (unsigned)(col.z0 + zp);   // first cell of the run (rows are 16-aligned)
+            seg0 = a0 & ~15u;
+            nseg = (int)(((a0 & 15u) + (unsigned)col.n + 15u) >> 4);
+            const unsigned carry = (((unsigned)col.z0 & 15u) + r) >> 4;
+            s0 = 16u * ((unsigned)col.voff + carry) - r;                        // byte offset of piece 0's values
+            cnt += col.cnt;                                                     // S3P:888: every beam is in range here
+            myci = (unsigned)ci;
+            pending = true;
+        };
+        if (lane < FC_SLOTS && lane < n_cols) take(cols[lane], lane);
+        next = min(n_cols, FC_SLOTS);
+        while (__any(pending)) {
             if (pending) {
                 unsigned sl = (key * 2654435761u) >> 24;
                 while (true) {
@@ -225,6 +228,14 @@ __global__ __launch_bounds__(256) void k_measure_fuse_cols(
             }
             __builtin_amdgcn_wave_barrier();
             if (stats && lane == 0) atomicAdd(&stats[1], 1u);
+            // the winners' lanes are free after this round: their next columns of the list, asked for now and
+            // set up while this round's stores are on their way
+            const unsigned long long freem = __ballot(winner);
+            const int nci = next + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
+            const bool more = winner && nci < n_cols;
+            PfFCol ncol{};
+            if (more) ncol = cols[nci];
+            next = min(n_cols, next + (int)__popcll(freem));
             // The winners' runs, a lane per 16-byte piece: pass k gives the FC_LPC lanes FC_LPC j .. of the wave
             // the pieces of the column held by lane FC_CPP k + j, so the lanes of a wave instruction read whole
             // 64-byte lines where the map columns are neighbours (z is the fastest axis, then y; with 80 cells
@@ -233,44 +244,48 @@ __global__ __launch_bounds__(256) void k_measure_fuse_cols(
             // it once the earlier stores are acknowledged (the wait below).
             const int sub = lane / FC_LPC, qn = lane - sub * FC_LPC;
             const int wn = winner ? nseg : 0;
-            uint4 mc[FC_PASSES];
-            u4a vq[FC_PASSES], oq[FC_PASSES];
-            unsigned v5[FC_PASSES], o5[FC_PASSES], at[FC_PASSES];
-            bool act[FC_PASSES];
-#pragma unroll
-            for (int k = 0; k < FC_PASSES; ++k) {                       // every load of the round in flight together
+            // FC_DEPTH passes in flight: pass k + FC_DEPTH is asked for when pass k has been written back
+            uint4 mc[FC_DEPTH];
+            u4a vq[FC_DEPTH];
+            unsigned v5[FC_DEPTH], at[FC_DEPTH];
+            bool act[FC_DEPTH];
+            auto ask = [&](int k, int b) {
                 const int from = FC_CPP * k + sub;
                 const int n_k = __shfl(wn, from, 64);
                 const unsigned sv = __shfl(s0, from, 64) + 16u * (unsigned)qn;
-                at[k] = __shfl(seg0, from, 64) + 16u * (unsigned)qn;
-                act[k] = sub < FC_CPP && qn < n_k;
-                mc[k] = make_uint4(0, 0, 0, 0); vq[k] = (u4a)(0u); oq[k] = (u4a)(0u); v5[k] = 0; o5[k] = 0;
-                if (act[k]) {
+                at[b] = __shfl(seg0, from, 64) + 16u * (unsigned)qn;
+                act[b] = sub < FC_CPP && qn < n_k;
+                if (act[b]) {
                     const unsigned* vw = (const unsigned*)(vals + (sv & ~3u));
-                    const unsigned* ow = (const unsigned*)(occ + (sv & ~3u));
-                    mc[k] = *(const uint4*)(map + at[k]);
-                    vq[k] = *(const u4a*)vw; v5[k] = vw[4];
-                    oq[k] = *(const u4a*)ow; o5[k] = ow[4];
+                    mc[b] = *(const uint4*)(map + at[b]);
+                    vq[b] = *(const u4a*)vw; v5[b] = vw[4];
                 }
-            }
+            };
+            auto finish = [&](int b) {
+                if (act[b]) {
+                    const unsigned cw[4] = {mc[b].x, mc[b].y, mc[b].z, mc[b].w};
+                    const unsigned vd[5] = {vq[b].x, vq[b].y, vq[b].z, vq[b].w, v5[b]};
+                    unsigned o[4];
+                    us2 acc = (us2)((unsigned short)0);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        o[d] = fuse_dword(cw[d], __builtin_amdgcn_alignbyte(vd[d + 1], vd[d], bsh), lo2, hi2, thr2, acc);
+                    sum += (int)acc.x + (int)acc.y;
+                    uint4 ov; ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+                    // a piece no beam changed (saturated cells, S3P:896-901) is not written back
+                    const bool same = ((o[0] ^ cw[0]) | (o[1] ^ cw[1]) | (o[2] ^ cw[2]) | (o[3] ^ cw[3])) == 0u;
+                    if (!same) *(uint4*)(map + at[b]) = ov;
+                }
+            };
+#pragma unroll
+            for (int k = 0; k < FC_DEPTH; ++k) ask(k, k);
 #pragma unroll
             for (int k = 0; k < FC_PASSES; ++k) {
-                if (act[k]) {
-                    const unsigned cw[4] = {mc[k].x, mc[k].y, mc[k].z, mc[k].w};
-                    const unsigned vd[5] = {vq[k].x, vq[k].y, vq[k].z, vq[k].w, v5[k]};
-                    const unsigned od[5] = {oq[k].x, oq[k].y, oq[k].z, oq[k].w, o5[k]};
-                    unsigned o[4];
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const unsigned v4 = __builtin_amdgcn_alignbyte(vd[d + 1], vd[d], bsh);
-                        const unsigned o4 = __builtin_amdgcn_alignbyte(od[d + 1], od[d], bsh);
-                        o[d] = fuse_dword(cw[d], v4, o4, lo2, hi2, sum);
-                    }
-                    uint4 ov; ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
-                    *(uint4*)(map + at[k]) = ov;
-                }
+                finish(k % FC_DEPTH);
+                if (k + FC_DEPTH < FC_PASSES) ask(k + FC_DEPTH, k % FC_DEPTH);
             }
             if (winner) pending = false;
+            if (more) take(ncol, nci);
             // the stores of this round reach L2 before any later load of this wave is issued
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -284,16 +299,16 @@ __global__ __launch_bounds__(256) void k_measure_fuse_cols(
 
 hipError_t pfk_measure_fuse_cols(hipStream_t st, const double* pose, int P, uint8_t* maps, unsigned long long map_stride,
                                  const PfBeam* beams, int M, const PfFCol* cols, int n_cols, const void* vals,
-                                 const void* occ, PfFColBounds bd, int gx, int gy, int gz, PfGridParams gp, int2* partial) {
-    // SLAM_PF_FCOL_STATS=1 (development): particles walked beam by beam, election rounds
-    static const bool want_stats = getenv("SLAM_PF_FCOL_STATS") && atoi(getenv("SLAM_PF_FCOL_STATS")) != 0;
+                                 PfFColBounds bd, int gx, int gy, int gz, PfGridParams gp, int2* partial) {
+    // SLAM_PF_FCOL_STATS=1 (development, tests): particles walked beam by beam and rounds, on stderr
+    const bool want_stats = getenv("SLAM_PF_FCOL_STATS") && atoi(getenv("SLAM_PF_FCOL_STATS")) != 0;
     unsigned* stats = nullptr;
     if (want_stats) {
         if (hipMalloc((void**)&stats, 16) != hipSuccess) return hipGetLastError();
         (void)hipMemsetAsync(stats, 0, 16, st);
     }
     hipLaunchKernelGGL(k_measure_fuse_cols, dim3((P + 3) / 4), dim3(256), 0, st, pose, P, maps, map_stride, beams, M, cols,
-                       n_cols, (const unsigned char*)vals, (const unsigned char*)occ, bd, gx, gy, gz, gp, partial, stats);
+                       n_cols, (const unsigned char*)vals, bd, gx, gy, gz, gp, partial, stats);
     const hipError_t e = hipGetLastError();
     if (want_stats) {
         unsigned hs[4] = {0, 0, 0, 0};

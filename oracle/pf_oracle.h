@@ -8,10 +8,14 @@
  *     own particle_map() (S3P:827-962) and resample() (S3P:757-821), compiled from the
  *     reference's text by oracle/build_ref.sh and run in the build container; vectors in
  *     tests/golden/ (generator: oracle/make_golden.py).
- *   pfo_update_map / pfo_scan_vote / pfo_ring_* — PARITY UNPINNED: build_local_map (S3P:621-710) and
- *     scan_localization (S3P:300-410) are members of a class whose other members are ROS
- *     types, ROS is absent from this image and no stand-in may be written, and the reference
- *     holds no test or golden vector. They restate the cited lines as read.
+ *   pfo_update_map / pfo_scan_vote / pfo_ring_* / pfo_depth_to_cloud / pfo_read_occupied — PINNED
+ *     against the reference's class Slam: build_local_map (S3P:621-710), scan_localization
+ *     (S3P:300-410), scan_localization_map_update (S3P:412-530), the body of callback() (S3P:562-612)
+ *     and update_realtime_pos (S3P:712-728), compiled from the class's own text without its ROS
+ *     members by oracle/build_ref.sh (+ oracle/ref_harness_slam.cpp: one Slam object and accessors) and
+ *     run in the build container; vectors in tests/golden/{helpers_p,depth,vote,local_map,ring,frames}.npz
+ *     (generator: oracle/make_golden_frontend.py). frames.npz is 48 consecutive frames of the whole
+ *     callback() + particle_map() loop.
  *
  * Deliberate, documented deviations from the reference's undefined behaviour:
  *   D1  S3P:882 accepts flat == p_map_elements (one byte past the map). Here it is out of

@@ -130,10 +130,10 @@ def cpu_baseline(sc, dims, P, M, seconds):
 
 
 def k1_traffic(P, M, grid):
-    """HBM-side bytes per K1 launch from the committed PMC passes (profiles/r1_k1_traffic.json,
+    """HBM-side bytes per K1 launch from the committed PMC passes (profiles/r2_k1_traffic.json,
     made by tools/pmc_k1.sh), or None when this run is not the workload they were taken on."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_k1_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r2_k1_traffic.json")) as f:
             t = json.load(f)
     except OSError:
         return None

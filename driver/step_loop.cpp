@@ -164,7 +164,6 @@ int main(int argc, char** argv) {
                 const double zyx_now[3] = {yaw_scan, 0.0, 0.0};
                 CK(loc, pf_ring_update(loc, cloud.data(), n, pos_scan, zyx_now, &flags));       // S3P:419-529
                 keyframes += flags & 1;
-                if (flags & 2) { vote_loc[0] = pos_scan[0]; vote_loc[1] = pos_scan[1]; vote_loc[2] = pos_scan[2]; }
             }
             // build_local_map(): S3P:621-710
             pfh_draw_indices(rd(), (int64_t)ray_idx.size(), (int32_t)(n > 0 ? n - 1 : 0), ray_idx.data());   // S3P:666-669
@@ -174,12 +173,7 @@ int main(int argc, char** argv) {
             const double lzyx[3] = {local_yaw, 0.0, 0.0};
             CK(h, pf_set_scan(h, cloud.data(), n, ray_idx.data(), n > 0 ? (int64_t)ray_idx.size() : 0));
             CK(h, pf_update_map(h, PF_GRID_LOCAL, &upd, local_pos, lzyx));                      // S3P:628-704
-            pos[0] += std::cos(pos[3]) * pos_diff_scan[0] - std::sin(pos[3]) * pos_diff_scan[1] + diff[0];   // S3P:712-716
-            pos[1] += std::sin(pos[3]) * pos_diff_scan[0] + std::cos(pos[3]) * pos_diff_scan[1] + diff[1];
-            pos[2] += pos_diff_scan[2] + diff[2];
-            pos[3] += yaw_diff + diff[3];
-            if (pos[3] > pi) pos[3] -= 2 * pi; else if (pos[3] < -pi) pos[3] += 2 * pi;
-            for (double& v : diff) v = 0;
+            pfh_update_realtime_pos(pos, &pos[3], pos_diff_scan, yaw_diff, diff);              // S3P:712-728
         }
         // ---- particle_map() (S3P:827-962) ----
         double p_local[4], p_pos[4];

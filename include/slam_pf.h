@@ -297,7 +297,12 @@ int pf_sequential_cdf(pf_handle* h, const double* w, int64_t n, int32_t how, dou
  * to the other ranks by whatever channel the host program has; every rank then calls pf_comm_init.
  * After that pf_weights(h, NULL) all-gathers the scores (8 B per particle) and pf_resample(h, u,
  * NULL, ...) all-gathers the pose blocks (72 B per particle) itself, with RCCL on the handle's
- * stream. RCCL is loaded at run time (librccl.so.1); PF_ERR_NODEVICE when it is not there. */
+ * stream. RCCL is loaded at run time (librccl.so.1); PF_ERR_NODEVICE when it is not there.
+ * EXPERIMENTAL: the grouped all-gathers and the send/receive migration of per-particle maps have run
+ * on one rank only (the development box has one GPU); the same host logic is covered at world sizes 2
+ * and 4 over gloo with a test double (tests/test_sharded_gloo.py). Until a multi-GPU run is recorded,
+ * the documented default for sharded use is to do the two all-gathers yourself (torch.distributed or
+ * your own RCCL calls on pf_scores_device() / pf_poses_device()) and pass the gathered pointers. */
 int pf_comm_unique_id(void* id_out, int64_t capacity);
 int pf_comm_init(pf_handle* h, const void* id, int32_t rank, int32_t world);
 

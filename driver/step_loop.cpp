@@ -77,7 +77,6 @@ int main(int argc, char** argv) {
     const int steps = argc > 1 ? std::atoi(argv[1]) : 20;
     const int P = argc > 2 ? std::atoi(argv[2]) : 50;
     const bool truth_odometry = argc > 3 && std::strcmp(argv[3], "truth") == 0;
-    const double pi = 2 * std::acos(0.0);
 
     // ---- the filter: S3P:23-69 ----
     pf_config cfg;

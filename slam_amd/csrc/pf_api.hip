@@ -174,6 +174,7 @@ struct pf_handle {
     int k1_mode = 0;                   // SLAM_PF_K1: 0 auto, 1 col (gather layout), 2 box (LDS) whenever possible
     double yaw_hint = 0.0;             // mean yaw of the last host-side predict: aligns the clusters with the grid
     int n_cols = 0;
+    int n_runs = 0;                    // beams_col[0 .. n_runs): run groups (8-cell z windows)
     int col_ends[4] = {0, 0, 0, 0};    // ends of the 4-, 3-, 2-, 1-beam groups in beams_col
     int M_occ = 0;                     // padded to a multiple of PF_BEAM_GROUP
     int M_occ_real = 0;
@@ -966,22 +967,47 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         h->h_beams_occ_f.push_back(PfBeamF{-3.0e7f, 0.f, 0.f, 0});
     }
     const size_t no = h->h_beams_occ.size();
-    // column groups: runs of the list that share (lx, ly), at most four beams each, lz ascending
-    // inside a group; groups with more beams first (k_measure_col's phases), and dealing a phase
-    // round-robin gives every chunk the same share of it
+    // column groups: the occupied beams of one local column (a run of the list that shares (lx, ly)), lz
+    // ascending. An 8-cell z window that holds at least PF_RUN_MIN of them becomes a RUN group (three
+    // dword gathers for the whole window, k_measure_col's run phase); the others go four to a group;
+    // groups with more beams first (k_measure_col's phases), and dealing a phase round-robin gives every
+    // chunk the same share of it
     h->h_cols.clear();
-    for (int j = 0; j < n_real_occ;) {
-        const PfBeam& b0 = h->h_beams_occ[(size_t)j];
-        PfColG g{};
-        g.lx = (float)b0.lx; g.ly = (float)b0.ly; g.n = 0;
-        while (j < n_real_occ && g.n < 4 && h->h_beams_occ[(size_t)j].lx == b0.lx &&
-               h->h_beams_occ[(size_t)j].ly == b0.ly) {
-            g.lz[g.n++] = (int32_t)h->h_beams_occ[(size_t)j].lz;
-            ++j;
+    std::vector<PfColG> runs;
+    static const bool use_runs = !(getenv("SLAM_PF_RUNS") && atoi(getenv("SLAM_PF_RUNS")) == 0);
+    {
+        std::vector<int32_t> zs, rest;
+        for (int j = 0; j < n_real_occ;) {
+            const PfBeam& b0 = h->h_beams_occ[(size_t)j];
+            zs.clear(); rest.clear();
+            while (j < n_real_occ && h->h_beams_occ[(size_t)j].lx == b0.lx && h->h_beams_occ[(size_t)j].ly == b0.ly)
+                zs.push_back((int32_t)h->h_beams_occ[(size_t)j++].lz);
+            std::sort(zs.begin(), zs.end());
+            bool distinct = true;                                    // a cell listed twice counts twice: no mask for that
+            for (size_t i = 1; i < zs.size(); ++i) distinct = distinct && zs[i] != zs[i - 1];
+            for (size_t i = 0; i < zs.size();) {
+                size_t k = i;
+                while (k < zs.size() && zs[k] < zs[i] + 8) ++k;
+                if (use_runs && distinct && k - i >= PF_RUN_MIN) {
+                    PfColG g{};
+                    g.lx = (float)b0.lx; g.ly = (float)b0.ly; g.n = (int32_t)(k - i); g.lz[0] = zs[i];
+                    unsigned long long m = 0;
+                    for (size_t q = i; q < k; ++q) m |= 1ull << (8 * (zs[q] - zs[i]));
+                    g.lz[1] = (int32_t)(unsigned)m; g.lz[2] = (int32_t)(unsigned)(m >> 32); g.lz[3] = zs[k - 1];
+                    runs.push_back(g);
+                    i = k;
+                } else {
+                    rest.push_back(zs[i++]);
+                }
+            }
+            for (size_t i = 0; i < rest.size(); i += 4) {
+                PfColG g{};
+                g.lx = (float)b0.lx; g.ly = (float)b0.ly; g.n = (int32_t)std::min<size_t>(4, rest.size() - i);
+                for (int k = 0; k < g.n; ++k) g.lz[k] = rest[i + (size_t)k];
+                for (int k = g.n; k < 4; ++k) g.lz[k] = g.lz[g.n - 1];
+                h->h_cols.push_back(g);
+            }
         }
-        std::sort(g.lz, g.lz + g.n);
-        for (int k = g.n; k < 4; ++k) g.lz[k] = g.lz[g.n - 1];
-        h->h_cols.push_back(g);
     }
     build_clusters(h, n_real_occ);
     build_fuse_columns(h);
@@ -991,9 +1017,15 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         if (a.n != b.n) return a.n > b.n;
         return a.lx * a.lx + a.ly * a.ly > b.lx * b.lx + b.ly * b.ly;
     });
+    // the run groups go in front (the longest trips first), farthest first like the others
+    std::stable_sort(runs.begin(), runs.end(), [](const PfColG& a, const PfColG& b) {
+        return a.lx * a.lx + a.ly * a.ly > b.lx * b.lx + b.ly * b.ly;
+    });
+    h->n_runs = (int)runs.size();
+    h->h_cols.insert(h->h_cols.begin(), runs.begin(), runs.end());
     h->n_cols = (int)h->h_cols.size();
     {
-        int e = 0;
+        int e = h->n_runs;
         for (int n = 4; n >= 1; --n) {
             while (e < h->n_cols && h->h_cols[(size_t)e].n == n) ++e;
             h->col_ends[4 - n] = e;
@@ -1122,7 +1154,7 @@ int pf_measure(pf_handle* h, int add_points) {
             if (cch > (h->n_cols + 11) / 12) cch = (h->n_cols + 11) / 12;
             if (cch < 1) cch = 1;
             chunks = cch;
-            HIP_TRY(h, pfk_measure_col(h->stream, h->sorted, h->P, h->shadow, h->swz, h->beams_col, h->col_ends,
+            HIP_TRY(h, pfk_measure_col(h->stream, h->sorted, h->P, h->shadow, h->swz, h->beams_col, h->n_runs, h->col_ends,
                                        chunks, grid_params(h), h->lmax_occ, h->order, h->partial));
         }
         else if (fuse && h->n_fcols > 0)

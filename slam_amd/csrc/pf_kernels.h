@@ -115,10 +115,13 @@ __device__ inline int order_key(const double* __restrict__ pose, int n, int i, P
 hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, int32_t* hist,
                      int32_t* next_hist, int32_t* order, double* sorted, PfOrderParams op,
                      bool hist_counted);
-// K1 on the gather layout (shared grid only), the beams grouped by column (PfColG) and the groups
-// sorted by their number of beams: group_ends = ends of the 4-, 3-, 2- and 1-beam groups in cg[].
+// K1 on the gather layout (shared grid only), the beams grouped by column (PfColG): cg[0 .. n_runs) are
+// RUN groups (the occupied cells of one column inside an 8-cell z window: lz[0] = first z, lz[1], lz[2] =
+// a byte of 1 per occupied cell 0-3, 4-7, n = their number), then the plain groups sorted by their number
+// of beams: group_ends = ends of the 4-, 3-, 2- and 1-beam groups in cg[].
+#define PF_RUN_MIN 4            // beams an 8-cell window must hold to become a run group (three gathers)
 hipError_t pfk_measure_col(hipStream_t st, const double* sorted, int P, const uint8_t* shadow,
-                           PfSwz sw, const PfColG* cg, const int group_ends[4], int n_chunks,
+                           PfSwz sw, const PfColG* cg, int n_runs, const int group_ends[4], int n_chunks,
                            PfGridParams gp, double lmax, const int32_t* order, int2* partial);
 // K1 on LDS-staged boxes of the reference-order shared grid (pf_measure_box.hip). cl: the clusters,
 // ordered by blockIdx.y group; group_start: int [groups + 1] into cl. partial_l: int2 [groups][P] in

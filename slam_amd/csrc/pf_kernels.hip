@@ -412,6 +412,93 @@ __device__ __forceinline__ void col_trip(const PfColG* __restrict__ cg, int g, c
         }
     }
 }
+// A RUN group: the occupied beams of one local column inside an 8-cell z window (lz[0] = first z of the
+// window, lz[1] / lz[2] = a byte of 1 per occupied cell 0-3 / 4-7, n = their number). The bricks keep the
+// four z-consecutive cells of an (X, Y) in one dword, so the window's cells are three dword gathers
+// (the z-quads of its first cell, the next one and of its last cell) for up to eight evaluations; the
+// window is cut out with two v_alignbyte by the lane's own Z & 3 and summed with two byte dot products.
+template <int T>
+__device__ __forceinline__ void run_trip(const PfColG* __restrict__ cg, int g, const ColLane& L,
+                                         const ColGrid& G, const PfGridParams& gp,
+                                         const uint8_t* __restrict__ shadow, int& sum, int& cnt) {
+    PfColG col[T];
+#pragma unroll
+    for (int q = 0; q < T; ++q) col[q] = cg[g + q];              // wave-uniform: scalar loads
+    int X[T], Y[T], Z0[T];
+    float fx[T], fy[T];
+    bool fine = true;
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+        const v2f lxx = {col[q].lx, col[q].lx}, lyy = {col[q].ly, col[q].ly};
+        const v2f h = __builtin_elementwise_fma(L.rotA, lxx, __builtin_elementwise_fma(L.rotB, lyy, L.trh));
+        X[q] = cvt_floor_i32(h.x); Y[q] = cvt_floor_i32(h.y);
+        fx[q] = __builtin_amdgcn_fractf(h.x); fy[q] = __builtin_amdgcn_fractf(h.y);
+        Z0[q] = col[q].lz[0] + L.zp;
+        const unsigned zm = max((unsigned)Z0[q], (unsigned)(Z0[q] + 7));
+        fine = fine & (__builtin_fminf(fx[q], fy[q]) >= L.E) & (__builtin_fmaxf(fx[q], fy[q]) <= L.hi) &
+               ((unsigned)X[q] < G.gx) & ((unsigned)Y[q] < G.gy) & (zm < G.gz);
+    }
+    if (__builtin_expect(__all(fine), 1)) {
+        unsigned d[T][3];
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            const unsigned base = swz_col_base((unsigned)X[q], (unsigned)Y[q], G.a, G.b) & ~3u;
+            const unsigned q0 = ((unsigned)Z0[q] >> 2) << 6, q2 = ((unsigned)(Z0[q] + 7) >> 2) << 6;
+            d[q][0] = *(const unsigned*)(shadow + (base + q0));
+            d[q][1] = *(const unsigned*)(shadow + (base + q0 + 64u));
+            d[q][2] = *(const unsigned*)(shadow + (base + q2));
+        }
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            const unsigned sh = (unsigned)Z0[q] & 3u;
+            const unsigned lo = __builtin_amdgcn_alignbyte(d[q][1], d[q][0], sh);
+            const unsigned hi = __builtin_amdgcn_alignbyte(d[q][2], d[q][1], sh);
+            sum = (int)__builtin_amdgcn_udot4(hi, (unsigned)col[q].lz[2],
+                                              __builtin_amdgcn_udot4(lo, (unsigned)col[q].lz[1], (unsigned)sum, false), false);   // S3P:887
+            cnt += col[q].n;                                                                                   // S3P:888
+        }
+        return;
+    }
+    // some lane is near a rounding boundary or off an axis: beam by beam
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+        const double dlx = (double)col[q].lx, dly = (double)col[q].ly;   // exact: integers below 2^24
+        const unsigned long long occ = ((unsigned long long)(unsigned)col[q].lz[2] << 32) | (unsigned)col[q].lz[1];
+        for (int k = 0; k < 8; ++k) {
+            if (!((occ >> (8 * k)) & 1ull)) continue;                  // wave-uniform
+            unsigned xc = (unsigned)X[q], yc = (unsigned)Y[q], zc = (unsigned)(Z0[q] + k);
+            bool ok = (xc < G.gx) & (yc < G.gy) & (zc < G.gz);
+            const bool good = (__builtin_fminf(fx[q], fy[q]) >= L.E) & (__builtin_fmaxf(fx[q], fy[q]) <= L.hi) & ok;
+            if (__any(!good)) {
+                // reference sequence S3P:745-747, 880, 85, then the cell the flat index names
+                const double Xd = round((L.c * dlx + L.ms * dly) + L.tx);
+                const double Yd = round((L.s * dlx + L.c * dly) + L.ty);
+                const double Zd = round((double)(col[q].lz[0] + k) + L.tz);
+                const double fd = fma(Xd, gp.gyz, fma(Yd, gp.gzd, Zd));
+                ok = (fd >= 0.0) & (fd < gp.elements);                 // S3P:882
+                const unsigned f = ok ? (unsigned)fd : 0u;
+                xc = f / (G.gy * G.gz);
+                const unsigned r = f - xc * (G.gy * G.gz);
+                yc = r / G.gz;
+                zc = r - yc * G.gz;
+            }
+            const unsigned vv = shadow[ok ? swz_addr(xc, yc, zc, G.a, G.b) : 0u];
+            sum += ok ? (int)vv : 0;
+            cnt += ok ? 1 : 0;
+        }
+    }
+}
+// The run groups [0, g1): dealt to the chunks in pairs like the phases below.
+__device__ __forceinline__ void run_phase(const PfColG* __restrict__ cg, int g1, const ColLane& L,
+                                          const ColGrid& G, const PfGridParams& gp,
+                                          const uint8_t* __restrict__ shadow, int& sum, int& cnt) {
+    const int C = (int)gridDim.y;
+    for (int pp = (int)blockIdx.y; 2 * pp < g1; pp += C) {
+        if (2 * pp + 2 <= g1) run_trip<2>(cg, 2 * pp, L, G, gp, shadow, sum, cnt);
+        else run_trip<1>(cg, 2 * pp, L, G, gp, shadow, sum, cnt);
+    }
+}
+
 // One phase: the groups [g0, g1) all have N beams.
 template <int N>
 __device__ __forceinline__ void col_phase(const PfColG* __restrict__ cg, int g0, int g1, const ColLane& L,
@@ -429,7 +516,7 @@ __device__ __forceinline__ void col_phase(const PfColG* __restrict__ cg, int g0,
     }
 }
 
-// ends = {end of the 4-beam groups, of the 3-, of the 2-, of the 1-beam groups} in cg[]
+// cg[] = run groups [0, runs), then ends = {end of the 4-beam groups, of the 3-, of the 2-, of the 1-beam groups}
 // (waves_per_eu 8: the launch is sized as one residency of eight 256-thread blocks per CU, so the
 // register budget is 64 whatever the code does; stated to the compiler it also schedules the
 // loop tighter: 29.8 against 30.5 us at configs[1], 1.16 against 1.30 ms at configs[4]'s share.
@@ -437,7 +524,7 @@ __device__ __forceinline__ void col_phase(const PfColG* __restrict__ cg, int g0,
 // case in the slow branch, 1.45 ms at configs[4]'s share, where a fifth of the trips take it.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_measure_col(
         const double* __restrict__ sorted, int P, const uint8_t* __restrict__ shadow, PfSwz sw,
-        const PfColG* __restrict__ cg, int4 ends, PfGridParams gp,
+        const PfColG* __restrict__ cg, int runs, int4 ends, PfGridParams gp,
         double lmax, const int32_t* __restrict__ order, int2* __restrict__ partial,
         unsigned long long* __restrict__ trace) {
     // (raised before the prologue: a wave that still loads its pose while its neighbours already
@@ -471,7 +558,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // (Tried instead, and slower: a per-slot work queue that hands beam batches to whichever
     // wave is free, 44 us against 39 us, the same-address atomics cost more than the tail;
     // an XCD-aware chunk map so each L2 sees an eighth of the beams, no measurable change.)
-    col_phase<4>(cg, 0, ends.x, L, G, gp, shadow, sum, cnt);
+    run_phase(cg, runs, L, G, gp, shadow, sum, cnt);
+    col_phase<4>(cg, runs, ends.x, L, G, gp, shadow, sum, cnt);
     __builtin_amdgcn_s_setprio(2);
     col_phase<3>(cg, ends.x, ends.y, L, G, gp, shadow, sum, cnt);
     __builtin_amdgcn_s_setprio(1);
@@ -592,7 +680,7 @@ hipError_t pfk_measure_fast(hipStream_t st, const double* pose, int P, const uin
 }
 
 hipError_t pfk_measure_col(hipStream_t st, const double* sorted, int P, const uint8_t* shadow,
-                           PfSwz sw, const PfColG* cg, const int group_ends[4], int n_chunks,
+                           PfSwz sw, const PfColG* cg, int n_runs, const int group_ends[4], int n_chunks,
                            PfGridParams gp, double lmax, const int32_t* order, int2* partial) {
     // SLAM_PF_K1_TRACE=<file>: development aid, dumps {start, loop start, end, HW_ID} per wave
     static unsigned long long* trace = nullptr;
@@ -604,7 +692,7 @@ hipError_t pfk_measure_col(hipStream_t st, const double* sorted, int P, const ui
         (void)hipMemsetAsync(trace, 0, 8 * trace_n, st);
     }
     hipLaunchKernelGGL(k_measure_col, dim3((P + 255) / 256, n_chunks), dim3(256), 0, st, sorted, P, shadow,
-                       sw, cg, make_int4(group_ends[0], group_ends[1], group_ends[2], group_ends[3]), gp, lmax,
+                       sw, cg, n_runs, make_int4(group_ends[0], group_ends[1], group_ends[2], group_ends[3]), gp, lmax,
                        order, partial, trace_path ? trace : nullptr);
     if (trace_path) {
         (void)hipStreamSynchronize(st);

@@ -117,3 +117,38 @@ def test_saturated_maps_stay_put(capfd, monkeypatch):
     yaw = rng.uniform(-0.4, 0.4, P)
     grid0 = np.full(dims, 50, np.uint8)
     _run(capfd, monkeypatch, dims, beams, x, y, z, yaw, grid0, steps=4)
+
+
+def test_k1_run_groups_match_oracle():
+    """K1 on the shared grid (k_measure_col) with columns dense enough for its RUN groups (8-cell z windows
+    read as three dwords, pf_api.hip pf_set_beams): walls as tall z runs with holes, single cells, a cell
+    listed twice (no run for that column), particles in the middle at every yaw, at the rim, too high, too
+    low and on a z tie. Every score against the oracle."""
+    from slam_amd import capi, synth
+    from oracle import binding as O
+    rng = np.random.default_rng(11)
+    dims = (64, 64, 48)
+    bx, by, bz, bv = _dense_columns(rng, 7, -14, 14, hole=0.15)
+    bv = np.where(rng.random(len(bv)) < 0.7, np.int8(60), np.int8(5)).astype(np.int8)      # 30 % not occupied
+    bx = np.concatenate([bx, bx[:3]]); by = np.concatenate([by, by[:3]]); bz = np.concatenate([bz, bz[:3]])
+    bv = np.concatenate([bv, np.full(3, 60, np.int8)])                                         # repeated cells
+    grid = synth.make_room(dims, 1)
+    grid[rng.random(dims) < 0.3] = 77
+    P = 700
+    x = rng.uniform(1.5, 1.7, P); y = rng.uniform(1.5, 1.7, P); z = rng.uniform(1.1, 1.3, P)
+    yaw = rng.uniform(-3.2, 3.2, P)
+    x[:40] = rng.uniform(0.1, 0.4, 40); y[40:60] = 3.0; z[60:90] = 2.0; z[90:120] = 0.3
+    z[120:140] = (np.arange(20, 40) + 0.5) * 0.05
+    cfg = capi.default_config(n_particles=P, map_mode=capi.PF_MAP_SHARED, grid_x=dims[0], grid_y=dims[1],
+                              grid_z=dims[2], local_x=0, local_y=0, local_z=0, max_beams=len(bx))
+    h = capi.Handle(cfg)
+    try:
+        h.write_map(0, grid); h.predict(x, y, z, yaw); h.set_beams(bx, by, bz, bv)
+        h.measure(0)
+        gs, gc = h.get_scores()
+        g1 = grid.reshape(-1).copy()
+        s, c = O.measure(O.ref_grid(*dims), x, y, z, yaw, g1, 0, bx, by, bz, bv, 0)
+        assert np.array_equal(gs, s) and np.array_equal(gc, c)
+        assert len(np.unique(gc)) > 3
+    finally:
+        h.close()

@@ -61,7 +61,8 @@ def parse():
                          "step's snapshot), pf_set_scan, pf_predict (host poses: libm trig + upload) and the "
                          "thresholds, instead of inputs resident in HBM; reported in config, never the headline")
     ap.add_argument("--settle-seconds", type=float, default=1.0,
-                    help="untimed steps for this long before the warmup steps (host start-up effects of a fresh box)")
+                    help="untimed settling before the warmup steps: 5000 steps per unit (a step count, so that every rank enqueues "
+                         "the same collectives; about this many seconds on a fresh box, whose first process enqueues slowly)")
     ap.add_argument("--profile-steps", type=int, default=20,
                     help="steps of the second, untimed pass that times K3/K4/K5 with HIP events (0: skip)")
     ap.add_argument("--force-sharded", action="store_true",
@@ -288,10 +289,9 @@ def main():
     # untimed settling before the W warmup steps: the first process on a fresh box enqueues at less
     # than half its steady rate for the first few hundred steps (host side: the kernels' own times
     # are the same from the first launch)
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < a.settle_seconds:
-        for _ in range(50):
-            step()
+    # (a fixed number of steps, not a time: every rank must enqueue the same collectives)
+    for _ in range(int(a.settle_seconds * 5000)):
+        step()
     for _ in range(a.warmup):
         step()
     # K1 is timed live with HIP events on its stream (roofline); the other classes only on request

@@ -211,7 +211,7 @@ template <int KP>
 __global__ __launch_bounds__(BOX_WG) void k_measure_box(
         const double* __restrict__ sorted, int P, int Lp, const uint8_t* __restrict__ maps, int gx, int gy, int gz,
         const PfColG* __restrict__ cg, const PfCluster* __restrict__ cl, const int* __restrict__ group_start,
-        PfGridParams gp, double lmax, int2* __restrict__ partial_l, unsigned long long* __restrict__ stats, int dbg) {
+        PfGridParams gp, double lmax, int2* __restrict__ partial_l, unsigned long long* __restrict__ stats) {
     extern __shared__ unsigned box_lds[];                  // [2][BOX_CAP_DW], then uint4 [2][2 * BOX_COLCAP] column groups
     __shared__ float red_f[16][8];
     __shared__ int red_i[16][2];
@@ -276,7 +276,6 @@ __global__ __launch_bounds__(BOX_WG) void k_measure_box(
 #define TL_MARK() do { if (tl_on && tl < 120) stats[tl++] = wall_clock64(); } while (0)
     if (tl_on) stats[tl++] = t_begin;
     TL_MARK();
-    if (dbg & 16) return;
     const int c_begin = group_start[blockIdx.y], c_end = group_start[blockIdx.y + 1];
     int cnt_common = 0;                                     // beams every lane of this wave counted (fast columns)
     typedef __attribute__((address_space(1))) const unsigned g_u32;
@@ -331,7 +330,7 @@ __global__ __launch_bounds__(BOX_WG) void k_measure_box(
             if (ci + 1 < c_end) {
                 cn = cl[ci + 1];
                 nxt = box_uni(cn);
-                if (!(dbg & 2)) stage(nxt, cn, which ^ 1);
+                stage(nxt, cn, which ^ 1);
             }
             lds_u8* lds_b = (lds_u8*)(box_lds + which * BOX_CAP_DW);
             if (stats && tid == 0) {                     // development aid (SLAM_PF_BOX_STATS)
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(BOX_WG) void k_measure_box(
                 atomicAdd(&stats[2], (unsigned long long)cur.dwords); atomicAdd(&stats[3], (unsigned long long)(c.g1 - c.g0));
             }
             lds_u4* cols = (lds_u4*)(col_lds + which * 8 * BOX_COLCAP);
-            const int ng = (dbg & 1) ? 0 : c.g1 - c.g0;
+            const int ng = c.g1 - c.g0;
             const int sy = cur.ny * cur.nzq * 4, sz = cur.nzq * 4;
             const int K0 = -(cur.X0 * sy + cur.Y0 * sz + cur.Z0);
             int Kz[KP];
@@ -369,7 +368,7 @@ __global__ __launch_bounds__(BOX_WG) void k_measure_box(
                     else { if (ln == 0) my_slow[n_slow] = (unsigned short)g; ++n_slow; }
                 }
             }
-            const int n_second = (dbg & 32) ? 0 : fast ? n_slow : ng;
+            const int n_second = fast ? n_slow : ng;
 #pragma nounroll
             for (int i = 0; i < n_second; ++i) {
                 const int g = fast ? uni((int)my_slow[i]) : i;          // (written by this wave's lane 0 above)
@@ -451,7 +450,6 @@ hipError_t pfk_measure_box(hipStream_t st, const double* sorted, int P, const ui
     const dim3 grid(parts, groups);
     const size_t lds = 2 * BOX_CAP_DW * sizeof(unsigned) + 2 * 8 * BOX_COLCAP * sizeof(unsigned) + 16 * BOX_COLCAP * sizeof(unsigned short);
     static const bool want_stats = getenv("SLAM_PF_BOX_STATS") != nullptr;
-    static const int dbg = getenv("SLAM_PF_BOX_DBG") ? atoi(getenv("SLAM_PF_BOX_DBG")) : 0;
     unsigned long long* stats = nullptr;
     if (want_stats) {
         if (hipMalloc((void**)&stats, 1024) != hipSuccess) return hipErrorOutOfMemory;
@@ -459,7 +457,7 @@ hipError_t pfk_measure_box(hipStream_t st, const double* sorted, int P, const ui
     }
 #define LAUNCH_BOX(K)                                                                                        \
     hipLaunchKernelGGL((k_measure_box<K>), grid, dim3(BOX_WG), lds, st, sorted, P, lp, maps, gx, gy, gz, cg, cl, \
-                       group_start, gp, lmax, partial_l, stats, dbg)
+                       group_start, gp, lmax, partial_l, stats)
     if (kp == 2) LAUNCH_BOX(2);
     else LAUNCH_BOX(1);
 #undef LAUNCH_BOX

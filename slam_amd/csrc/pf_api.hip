@@ -449,7 +449,9 @@ bool box_eligible(const pf_handle* h);
 // kernel's conditions do not hold: the step then runs beam by beam (k_measure_fuse_wave).
 void build_fuse_columns(pf_handle* h) {
     h->h_fcols.clear(); h->h_fvals.clear(); h->n_fcols = 0;
-    static const bool off = getenv("SLAM_PF_FUSE_COLS") && atoi(getenv("SLAM_PF_FUSE_COLS")) == 0;
+    // SLAM_PF_FUSE_COLS: 0 never, 1 whenever the kernel's conditions hold, unset: when the list is dense enough
+    const char* knob = getenv("SLAM_PF_FUSE_COLS");
+    const bool off = knob && atoi(knob) == 0, forced = knob && atoi(knob) != 0;
     if (off || h->cfg.map_mode != PF_MAP_PER_PARTICLE || h->cfg.grid_z % 16 != 0 || h->slab % 16 != 0 ||
         h->elements >= 2147483648ll || h->h_beams.empty())
         return;
@@ -474,6 +476,10 @@ void build_fuse_columns(pf_handle* h) {
         j = k;
     }
     first.push_back(n);
+    // A column costs a 16-byte load and store per piece whatever it holds: on a sparse list (one beam per
+    // column: configs[3]'s 2048-beam scan, 2.1 ms against 1.5 ms) the beam-by-beam kernel is the faster one,
+    // on the reference's dense local maps (35 beams per column) the column form is 3.4 times faster.
+    if (!forced && (size_t)n < 4 * C.size()) { C.clear(); return; }
     // values and flag bytes, columns in list order (the kernel's election keeps the list's order per cell)
     std::vector<uint8_t>& V = h->h_fvals;
     V.assign(16, 0);

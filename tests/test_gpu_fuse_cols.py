@@ -38,6 +38,7 @@ def _run(capfd, monkeypatch, dims, beams, x, y, z, yaw, grid0, steps=2, **cfg_kw
     from slam_amd import capi
     from oracle import binding as O
     monkeypatch.setenv("SLAM_PF_FCOL_STATS", "1")
+    monkeypatch.setenv("SLAM_PF_FUSE_COLS", "1")           # also for lists too sparse for the automatic choice
     P = len(x)
     og = O.ref_grid(*dims, occ_threshold=cfg_kw.get("occ_threshold", 20), map_lo=cfg_kw.get("map_lo", 0),
                     map_hi=cfg_kw.get("map_hi", 100))

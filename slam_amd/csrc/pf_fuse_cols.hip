@@ -8,9 +8,9 @@
 // one contiguous run of bytes. k_measure_fuse_wave touches those bytes one beam at a time (a
 // 4-byte load and a 1-byte store per beam, an LDS election per beam); here the run is read as
 // 16-byte pieces, a lane per piece, every beam is applied to the bytes in registers (two cells per
-// packed 16-bit instruction, the occupied cells' sum as a byte dot product), and the pieces are
-// written back: one load and one store per 16 cells instead of 16 + 16, and the four lanes of a
-// column (and the columns next to it in y) share their 64-byte lines.
+// packed 16-bit instruction, the occupied cells' sum as packed 16-bit multiply-adds), and the
+// pieces are written back: one load and one store per 16 cells instead of 16 + 16, and the five
+// lanes of a column (and the columns next to it in y) share their cache lines.
 //
 // Order. The reference's sequential semantics (a beam reads its cell after every earlier beam's
 // add, S3P:886-904) only matter between beams that reach the same cell. With every column of the
@@ -19,12 +19,14 @@
 // order, exactly as k_measure_fuse_wave does), two columns can share cells only if they round to
 // the same (X, Y), which takes |dx| < 1 and |dy| < 1 after the rotation: local columns at distance
 // 0 or 1, i.e. the same (lx, ly) or 4-neighbours: a few per cent of the columns at most yaws.
-// One wave walks the columns of one particle in list order as a ROLLING batch: every round each free
-// lane takes the next column of the list (x, y, the key and the addresses are computed a lane per column), all 64 lanes enter an LDS election keyed by (X, Y) (the table
-// k_measure_fuse_wave uses per cell; the lowest column index wins), the winners read-modify-write their
-// runs in parallel and become free, the few losers stay for the next round, where they meet the newly
-// taken columns (all later in the list) and win against them. So every cell sees its columns in list
-// order, and a collision costs its loser one round of waiting instead of costing the whole wave a round.
+// One wave walks the columns of one particle in list order as a ROLLING batch: every round each
+// free lane takes the next column of the list (x, y, the key and the addresses are computed a lane
+// per column), all lanes that hold a column enter an LDS election keyed by (X, Y) (the table
+// k_measure_fuse_wave uses per cell; the lowest column index wins), the winners' runs are
+// read-modify-written in parallel and their lanes become free, the few losers stay for the next
+// round, where they meet the newly taken columns (all later in the list) and win against them.
+// So every cell sees its columns in list order, and a collision costs its loser one round of
+// waiting instead of costing the whole wave a round.
 // A round's stores are acknowledged before the next round's loads. Map rows are 16-byte aligned
 // (gz % 16 == 0 is required), so columns with different (X, Y) never share a 16-byte piece.
 //

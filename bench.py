@@ -61,7 +61,7 @@ def parse():
                          "step's snapshot), pf_set_scan, pf_predict (host poses: libm trig + upload) and the "
                          "thresholds, instead of inputs resident in HBM; reported in config, never the headline")
     ap.add_argument("--settle-seconds", type=float, default=1.0,
-                    help="untimed settling before the warmup steps: 5000 steps per unit (a step count, so that every rank enqueues "
+                    help="untimed settling before the warmup steps: 12000 steps per unit (a step count, so that every rank enqueues "
                          "the same collectives; about this many seconds on a fresh box, whose first process enqueues slowly)")
     ap.add_argument("--profile-steps", type=int, default=20,
                     help="steps of the second, untimed pass that times K3/K4/K5 with HIP events (0: skip)")
@@ -290,7 +290,7 @@ def main():
     # than half its steady rate for the first few hundred steps (host side: the kernels' own times
     # are the same from the first launch)
     # (a fixed number of steps, not a time: every rank must enqueue the same collectives)
-    for _ in range(int(a.settle_seconds * 5000)):
+    for _ in range(int(a.settle_seconds * 12000)):
         step()
     for _ in range(a.warmup):
         step()

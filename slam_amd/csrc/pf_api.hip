@@ -169,6 +169,13 @@ struct pf_handle {
     std::vector<PfFCol> h_fcols;
     std::vector<uint8_t> h_fvals;
     PfFColBounds fbounds{};
+    // the same for the occupied beams only (measure without the add)
+    PfFCol* mcols = nullptr;
+    uint8_t* mvals = nullptr;
+    std::vector<PfFCol> h_mcols;
+    std::vector<uint8_t> h_mvals;
+    PfFColBounds mbounds{};
+    int n_mcols = 0;
     int n_fcols = 0;                   // 0: the beam list does not qualify, k_measure_fuse_wave takes the step
     int partial_rows = 1;              // rows of `partial` (chunks of the col kernels / groups of the box kernel)
     int k1_mode = 0;                   // SLAM_PF_K1: 0 auto, 1 col (gather layout), 2 box (LDS) whenever possible
@@ -444,44 +451,37 @@ bool box_eligible(const pf_handle* h);
 // to the blockIdx.y groups, largest first onto the least loaded one. SLAM_PF_BOX=volume,mx,my,mz
 // overrides the budget (cells) and the margins (development knob). Any clustering gives the same
 // results; it only decides how much a workgroup stages per evaluation.
-// The full beam list as local columns for k_measure_fuse_cols: maximal runs that share (lx, ly) and
-// ascend strictly in lz (the order S3P:868-877 produces), cut at PF_FCOL_MAXZ cells. Left empty when the
-// kernel's conditions do not hold: the step then runs beam by beam (k_measure_fuse_wave).
-void build_fuse_columns(pf_handle* h) {
-    h->h_fcols.clear(); h->h_fvals.clear(); h->n_fcols = 0;
-    // SLAM_PF_FUSE_COLS: 0 never, 1 whenever the kernel's conditions hold, unset: when the list is dense enough
-    const char* knob = getenv("SLAM_PF_FUSE_COLS");
-    const bool off = knob && atoi(knob) == 0, forced = knob && atoi(knob) != 0;
-    if (off || h->cfg.map_mode != PF_MAP_PER_PARTICLE || h->cfg.grid_z % 16 != 0 || h->slab % 16 != 0 ||
-        h->elements >= 2147483648ll || h->h_beams.empty())
-        return;
-    const std::vector<PfBeam>& B = h->h_beams;
-    const int n = (int)B.size();
-    std::vector<PfFCol>& C = h->h_fcols;
+// A beam list as local columns for k_measure_fuse_cols: maximal runs that share (lx, ly) and ascend
+// strictly in lz (the order S3P:868-877 produces), cut at PF_FCOL_MAXZ cells. Returns false (outputs
+// empty) when the list does not qualify: a zero value (0 means "no beam" in the values), or fewer than
+// min_per_col beams per column on average. A column costs a 16-byte load (and store) per piece whatever
+// it holds: on a sparse list (one beam per column: configs[3]'s 2048-beam scan, 2.1 ms against 1.5 ms
+// with the add) the beam-by-beam kernels are faster, on the reference's dense local maps (35 beams per
+// column) the column form is 3.4 times faster.
+bool columns_of(const PfBeam* B, int n, int occ_threshold, int min_per_col, bool forced, std::vector<PfFCol>& C,
+                std::vector<uint8_t>& V, PfFColBounds& bd) {
+    C.clear(); V.clear();
+    if (n <= 0) return false;
     std::vector<int> first;                       // first beam of each column
-    PfFColBounds bd{(float)B[0].lx, (float)B[0].lx, (float)B[0].ly, (float)B[0].ly, (int32_t)B[0].lz, (int32_t)B[0].lz};
+    bd = PfFColBounds{(float)B[0].lx, (float)B[0].lx, (float)B[0].ly, (float)B[0].ly, (int32_t)B[0].lz, (int32_t)B[0].lz};
     for (int j = 0; j < n;) {
-        if (B[(size_t)j].v == 0) { C.clear(); return; }        // 0 means "no beam" in the values
+        if (B[j].v == 0) { C.clear(); return false; }
         PfFCol c{};
-        c.lx = (float)B[(size_t)j].lx; c.ly = (float)B[(size_t)j].ly;        // exact: |offset| <= 2^20
-        c.z0 = (int32_t)B[(size_t)j].lz;
+        c.lx = (float)B[j].lx; c.ly = (float)B[j].ly;        // exact: |offset| <= 2^20
+        c.z0 = (int32_t)B[j].lz;
         int k = j + 1;
-        while (k < n && B[(size_t)k].lx == B[(size_t)j].lx && B[(size_t)k].ly == B[(size_t)j].ly && B[(size_t)k].v != 0 &&
-               B[(size_t)k].lz > B[(size_t)k - 1].lz && (int32_t)B[(size_t)k].lz - c.z0 < PF_FCOL_MAXZ)
+        while (k < n && B[k].lx == B[j].lx && B[k].ly == B[j].ly && B[k].v != 0 && B[k].lz > B[k - 1].lz &&
+               (int32_t)B[k].lz - c.z0 < PF_FCOL_MAXZ)
             ++k;
-        c.n = (int32_t)B[(size_t)k - 1].lz - c.z0 + 1;
+        c.n = (int32_t)B[k - 1].lz - c.z0 + 1;
         bd.lx0 = fminf(bd.lx0, c.lx); bd.lx1 = fmaxf(bd.lx1, c.lx); bd.ly0 = fminf(bd.ly0, c.ly); bd.ly1 = fmaxf(bd.ly1, c.ly);
         bd.z0 = std::min(bd.z0, c.z0); bd.z1 = std::max(bd.z1, c.z0 + c.n - 1);
         C.push_back(c); first.push_back(j);
         j = k;
     }
     first.push_back(n);
-    // A column costs a 16-byte load and store per piece whatever it holds: on a sparse list (one beam per
-    // column: configs[3]'s 2048-beam scan, 2.1 ms against 1.5 ms) the beam-by-beam kernel is the faster one,
-    // on the reference's dense local maps (35 beams per column) the column form is 3.4 times faster.
-    if (!forced && (size_t)n < 4 * C.size()) { C.clear(); return; }
-    // values and flag bytes, columns in list order (the kernel's election keeps the list's order per cell)
-    std::vector<uint8_t>& V = h->h_fvals;
+    if (!forced && (size_t)n < (size_t)min_per_col * C.size()) { C.clear(); return false; }
+    // values, columns in list order (the kernel's election keeps the list's order per cell)
     V.assign(16, 0);
     for (size_t i = 0; i < C.size(); ++i) {
         PfFCol& c = C[i];
@@ -490,14 +490,30 @@ void build_fuse_columns(pf_handle* h) {
         c.voff = (int32_t)(base / 16);
         V.resize(base + (((size_t)(e + c.n) + 15) & ~(size_t)15) + 16, 0);     // the run's units and the zero unit behind them
         for (int q = first[i]; q < first[i + 1]; ++q) {
-            const size_t at = base + (size_t)(e + (int32_t)B[(size_t)q].lz - c.z0);
-            V[at] = (uint8_t)(int8_t)B[(size_t)q].v;
-            if (B[(size_t)q].v > h->cfg.occ_threshold) ++c.cnt;
+            V[base + (size_t)(e + (int32_t)B[q].lz - c.z0)] = (uint8_t)(int8_t)B[q].v;
+            if (B[q].v > occ_threshold) ++c.cnt;
         }
     }
-    V.resize(V.size() + 48, 0);         // the last column's loads run up to 31 bytes past its zero unit
-    h->fbounds = bd;
-    h->n_fcols = (int)C.size();
+    V.resize(V.size() + 48, 0);                                 // the last column's loads run up to 31 bytes past its zero unit
+    return true;
+}
+
+// The column forms of the step's list for per-particle maps: every beam (measure + fuse) and the occupied
+// beams only (measure alone). Left empty when the kernel's conditions do not hold: the step then runs
+// beam by beam (k_measure_fuse_wave, k_measure_fast).
+void build_fuse_columns(pf_handle* h, int n_real_occ) {
+    h->h_fcols.clear(); h->h_fvals.clear(); h->n_fcols = 0;
+    h->h_mcols.clear(); h->h_mvals.clear(); h->n_mcols = 0;
+    // SLAM_PF_FUSE_COLS: 0 never, 1 whenever the kernel's conditions hold, unset: when the list is dense enough
+    const char* knob = getenv("SLAM_PF_FUSE_COLS");
+    const bool off = knob && atoi(knob) == 0, forced = knob && atoi(knob) != 0;
+    if (off || h->cfg.map_mode != PF_MAP_PER_PARTICLE || h->cfg.grid_z % 16 != 0 || h->slab % 16 != 0 ||
+        h->elements >= 2147483648ll)
+        return;
+    if (columns_of(h->h_beams.data(), (int)h->h_beams.size(), h->cfg.occ_threshold, 4, forced, h->h_fcols, h->h_fvals, h->fbounds))
+        h->n_fcols = (int)h->h_fcols.size();
+    if (columns_of(h->h_beams_occ.data(), n_real_occ, h->cfg.occ_threshold, 2, forced, h->h_mcols, h->h_mvals, h->mbounds))
+        h->n_mcols = (int)h->h_mcols.size();
 }
 
 void build_clusters(pf_handle* h, int n_occ) {
@@ -729,7 +745,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
                             sizeof(PfBeamF) * (mb + PF_BEAM_GROUP) + sizeof(PfColG) * (mb + 1) + sizeof(PfCluster) * (mb + 1) +
                             sizeof(int) * 257;
         if (c.map_mode == PF_MAP_PER_PARTICLE)      // worst case, every beam a column of its own: 32 B + two units
-            h->beam_blk_bytes += 64 * 2 + sizeof(PfFCol) * mb + 32 * mb + 64;
+            h->beam_blk_bytes += 2 * (64 * 2 + sizeof(PfFCol) * mb + 32 * mb + 64);
         CREATE_TRY(hipMalloc((void**)&h->beam_blk, h->beam_blk_bytes));
         h->beams = (PfBeam*)h->beam_blk;       // (real offsets are set by every pf_set_beams)
     }
@@ -1016,7 +1032,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         }
     }
     build_clusters(h, n_real_occ);
-    build_fuse_columns(h);
+    build_fuse_columns(h, n_real_occ);
     // ... and inside a phase by range: how far the lanes of a wave spread over cache lines grows
     // with the beam's range, so neighbours in this order cost about the same and go to different chunks
     std::stable_sort(h->h_cols.begin(), h->h_cols.end(), [](const PfColG& a, const PfColG& b) {
@@ -1050,6 +1066,8 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
             {nullptr, h->h_group_start.data(), h->box_groups > 0 ? sizeof(int) * h->h_group_start.size() : 0},
             {nullptr, h->h_fcols.data(), h->n_fcols > 0 ? sizeof(PfFCol) * h->h_fcols.size() : 0},
             {nullptr, h->h_fvals.data(), h->n_fcols > 0 ? h->h_fvals.size() : 0},
+            {nullptr, h->h_mcols.data(), h->n_mcols > 0 ? sizeof(PfFCol) * h->h_mcols.size() : 0},
+            {nullptr, h->h_mvals.data(), h->n_mcols > 0 ? h->h_mvals.size() : 0},
         };
         size_t total = 64;
         for (const Seg& sg : segs) total += (sg.bytes + 63) & ~(size_t)63;
@@ -1057,7 +1075,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         char* slot = nullptr;
         HIP_TRY(h, h->st_beams.acquire(total, &slot));
         size_t off = 0;
-        char* dev_at[9];
+        char* dev_at[11];
         int k = 0;
         for (const Seg& sg : segs) {
             dev_at[k++] = h->beam_blk + off;
@@ -1070,6 +1088,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         h->beams_occ_f = (PfBeamF*)dev_at[3]; h->beams_colc = (PfColG*)dev_at[4]; h->clusters = (PfCluster*)dev_at[5];
         h->group_start = (int*)dev_at[6];
         h->fcols = (PfFCol*)dev_at[7]; h->fvals = (uint8_t*)dev_at[8];
+        h->mcols = (PfFCol*)dev_at[9]; h->mvals = (uint8_t*)dev_at[10];
         HIP_TRY(h, h->st_beams.commit(h->stream));
     }
     h->M = (int)n;
@@ -1124,7 +1143,9 @@ int pf_measure(pf_handle* h, int add_points) {
     }
     const PfOrderParams op = order_params(h);
     const bool small_keys = op.mode != 0 && op.bits == 4;      // 4096 buckets: fixed counter pair
-    if (!fuse && !h->force_exact_measure && h->order_dirty) {
+    // (the column form on per-particle maps is a wave per particle: no lane order to prepare)
+    const bool mcols = !fuse && h->cfg.map_mode == PF_MAP_PER_PARTICLE && h->n_mcols > 0 && !h->force_exact_measure;
+    if (!fuse && !mcols && !h->force_exact_measure && h->order_dirty) {
         Timed t(h, PF_K_ORDER);
         if (small_keys) {
             HIP_TRY(h, pfk_order(h->stream, h->pose, h->P, h->order_keys, h->order_hist[0], h->order_hist[1],
@@ -1166,10 +1187,16 @@ int pf_measure(pf_handle* h, int add_points) {
         else if (fuse && h->n_fcols > 0)
             HIP_TRY(h, pfk_measure_fuse_cols(h->stream, h->pose, h->P, h->maps, h->slab, h->beams, h->M, h->fcols, h->n_fcols,
                                              h->fvals, h->fbounds, h->cfg.grid_x, h->cfg.grid_y, h->cfg.grid_z,
-                                             grid_params(h), h->partial));
+                                             grid_params(h), h->partial, true));
         else if (fuse)
             HIP_TRY(h, pfk_measure(h->stream, h->pose, h->P, h->maps, h->slab, h->beams, h->M, 1, bpc,
                                    grid_params(h), true, h->partial));
+        else if (mcols) {
+            chunks = 1;                               // a wave per particle, one partial each
+            HIP_TRY(h, pfk_measure_fuse_cols(h->stream, h->pose, h->P, h->maps, h->slab, h->beams_occ, h->M_occ, h->mcols,
+                                             h->n_mcols, h->mvals, h->mbounds, h->cfg.grid_x, h->cfg.grid_y, h->cfg.grid_z,
+                                             grid_params(h), h->partial, false));
+        }
         else if (h->force_exact_measure)
             HIP_TRY(h, pfk_measure(h->stream, h->pose, h->P, h->maps, h->slab, h->beams_occ, Mk, chunks,
                                    bpc, grid_params(h), false, h->partial));

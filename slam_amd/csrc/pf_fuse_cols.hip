@@ -64,6 +64,7 @@ __device__ __forceinline__ bool zamb(double tz) {
 
 // beams [j0, j1) of one particle, beam by beam, in the reference's order (the election of
 // k_measure_fuse_wave per cell): the route of particles the column form cannot take.
+template <bool FUSE>
 __device__ __forceinline__ void fuse_beam_range(int j0, int j1, const PfBeam* __restrict__ beams, double c, double s,
                                              double tx, double ty, double tz, uint8_t* map, const PfGridParams& gp,
                                              unsigned* keys, unsigned* minl, int lane, int& sum, int& cnt) {
@@ -108,7 +109,7 @@ __device__ __forceinline__ void fuse_beam_range(int j0, int j1, const PfBeam* __
                 if (v > gp.occ_threshold) { sum += cell; cnt += 1; }   // S3P:886-889
                 int nv = cell + v;                                      // S3P:895-904
                 nv = nv < gp.lo ? gp.lo : (nv > gp.hi ? gp.hi : nv);
-                if (nv != cell) map[f] = (uint8_t)nv;
+                if (FUSE && nv != cell) map[f] = (uint8_t)nv;
                 pending = false;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -138,6 +139,9 @@ __device__ __forceinline__ unsigned fuse_dword(unsigned cells, unsigned vals, s2
     return __builtin_bit_cast(unsigned, r02) | (__builtin_bit_cast(unsigned, r13) << 8);
 }
 
+// FUSE = false: the same walk without the add (S3P:892 add_points == 0): the list then holds the occupied
+// beams only, nothing is written, so no two columns can interfere and there is no election.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void k_measure_fuse_cols(
         const double* __restrict__ pose, int P, uint8_t* maps, unsigned long long map_stride,
         const PfBeam* __restrict__ beams, int M, const PfFCol* __restrict__ cols, int n_cols,
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void k_measure_fuse_cols(
     }
     if (!inside) {
         if (stats && lane == 0) atomicAdd(&stats[0], 1u);
-        fuse_beam_range(0, M, beams, c, s, tx, ty, tz, map, gp, keys[wv], minl[wv], lane, sum, cnt);
+        fuse_beam_range<FUSE>(0, M, beams, c, s, tx, ty, tz, map, gp, keys[wv], minl[wv], lane, sum, cnt);
     } else {
         const unsigned r = (unsigned)zp & 15u;                                 // wave-uniform
         const unsigned bsh = (0u - r) & 3u;                                    // byte shift of the value windows
@@ -211,24 +215,27 @@ __global__ __launch_bounds__(256) void k_measure_fuse_cols(
         if (lane < FC_SLOTS && lane < n_cols) take(cols[lane], lane);
         next = min(n_cols, FC_SLOTS);
         while (__any(pending)) {
-            if (pending) {
-                unsigned sl = (key * 2654435761u) >> 24;
-                while (true) {
-                    const unsigned old = atomicCAS(&keys[wv][sl], FC_EMPTY, key);
-                    if (old == FC_EMPTY || old == key) break;
-                    sl = (sl + 1u) & (FC_TBL - 1u);
+            bool winner = pending;
+            if (FUSE) {
+                if (pending) {
+                    unsigned sl = (key * 2654435761u) >> 24;
+                    while (true) {
+                        const unsigned old = atomicCAS(&keys[wv][sl], FC_EMPTY, key);
+                        if (old == FC_EMPTY || old == key) break;
+                        sl = (sl + 1u) & (FC_TBL - 1u);
+                    }
+                    atomicMin(&minl[wv][sl], myci);
+                    slot = sl;
                 }
-                atomicMin(&minl[wv][sl], myci);
-                slot = sl;
+                __builtin_amdgcn_wave_barrier();
+                winner = pending && __hip_atomic_load(&minl[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == myci;
+                __builtin_amdgcn_wave_barrier();
+                if (pending) {
+                    __hip_atomic_store(&keys[wv][slot], FC_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_store(&minl[wv][slot], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
-            const bool winner = pending && __hip_atomic_load(&minl[wv][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == myci;
-            __builtin_amdgcn_wave_barrier();
-            if (pending) {
-                __hip_atomic_store(&keys[wv][slot], FC_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_store(&minl[wv][slot], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-            __builtin_amdgcn_wave_barrier();
             if (stats && lane == 0) atomicAdd(&stats[1], 1u);
             // the winners' lanes are free after this round: their next columns of the list, asked for now and
             // set up while this round's stores are on their way
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(256) void k_measure_fuse_cols(
                     uint4 ov; ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
                     // a piece no beam changed (saturated cells, S3P:896-901) is not written back
                     const bool same = ((o[0] ^ cw[0]) | (o[1] ^ cw[1]) | (o[2] ^ cw[2]) | (o[3] ^ cw[3])) == 0u;
-                    if (!same) *(uint4*)(map + at[b]) = ov;
+                    if (FUSE && !same) *(uint4*)(map + at[b]) = ov;
                 }
             };
 #pragma unroll
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(256) void k_measure_fuse_cols(
             if (winner) pending = false;
             if (more) take(ncol, nci);
             // the stores of this round reach L2 before any later load of this wave is issued
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (FUSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
 #pragma unroll
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(256) void k_measure_fuse_cols(
 
 hipError_t pfk_measure_fuse_cols(hipStream_t st, const double* pose, int P, uint8_t* maps, unsigned long long map_stride,
                                  const PfBeam* beams, int M, const PfFCol* cols, int n_cols, const void* vals,
-                                 PfFColBounds bd, int gx, int gy, int gz, PfGridParams gp, int2* partial) {
+                                 PfFColBounds bd, int gx, int gy, int gz, PfGridParams gp, int2* partial, bool fuse) {
     // SLAM_PF_FCOL_STATS=1 (development, tests): particles walked beam by beam and rounds, on stderr
     const bool want_stats = getenv("SLAM_PF_FCOL_STATS") && atoi(getenv("SLAM_PF_FCOL_STATS")) != 0;
     unsigned* stats = nullptr;
@@ -309,8 +316,12 @@ hipError_t pfk_measure_fuse_cols(hipStream_t st, const double* pose, int P, uint
         if (hipMalloc((void**)&stats, 16) != hipSuccess) return hipGetLastError();
         (void)hipMemsetAsync(stats, 0, 16, st);
     }
-    hipLaunchKernelGGL(k_measure_fuse_cols, dim3((P + 3) / 4), dim3(256), 0, st, pose, P, maps, map_stride, beams, M, cols,
-                       n_cols, (const unsigned char*)vals, bd, gx, gy, gz, gp, partial, stats);
+    if (fuse)
+        hipLaunchKernelGGL(k_measure_fuse_cols<true>, dim3((P + 3) / 4), dim3(256), 0, st, pose, P, maps, map_stride, beams, M,
+                           cols, n_cols, (const unsigned char*)vals, bd, gx, gy, gz, gp, partial, stats);
+    else
+        hipLaunchKernelGGL(k_measure_fuse_cols<false>, dim3((P + 3) / 4), dim3(256), 0, st, pose, P, maps, map_stride, beams, M,
+                           cols, n_cols, (const unsigned char*)vals, bd, gx, gy, gz, gp, partial, stats);
     const hipError_t e = hipGetLastError();
     if (want_stats) {
         unsigned hs[4] = {0, 0, 0, 0};

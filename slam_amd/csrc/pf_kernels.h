@@ -73,10 +73,11 @@ hipError_t pfk_measure(hipStream_t st, const double* pose, int P, uint8_t* maps,
                        unsigned long long map_stride, const PfBeam* beams, int M, int n_chunks,
                        int beams_per_chunk, PfGridParams gp, bool fuse, int2* partial);
 // K1+K2 column-wise on per-particle maps (pf_fuse_cols.hip). Needs gz % 16 == 0, map_stride % 16 == 0,
-// elements < 2^31, every beam value non-zero. partial: int2 [P].
+// elements < 2^31, every beam value non-zero. partial: int2 [P]. fuse = false: measure only (S3P:859-890),
+// beams/cols/vals then hold the occupied beams only and nothing is written.
 hipError_t pfk_measure_fuse_cols(hipStream_t st, const double* pose, int P, uint8_t* maps, unsigned long long map_stride,
                                  const PfBeam* beams, int M, const PfFCol* cols, int n_cols, const void* vals,
-                                 PfFColBounds bd, int gx, int gy, int gz, PfGridParams gp, int2* partial);
+                                 PfFColBounds bd, int gx, int gy, int gz, PfGridParams gp, int2* partial, bool fuse);
 // The occupied-beam lists are padded to a multiple of PF_BEAM_GROUP with out-of-bounds beams;
 // M and bpc passed to pfk_measure_fast are multiples of it.
 #define PF_BEAM_GROUP 4

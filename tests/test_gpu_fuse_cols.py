@@ -61,6 +61,14 @@ def _run(capfd, monkeypatch, dims, beams, x, y, z, yaw, grid0, steps=2, **cfg_kw
             assert np.array_equal(gs, s) and np.array_equal(gc, c), step
             for i in range(P):
                 assert np.array_equal(h.read_map(i), maps[i]), (step, i)
+        # measure alone (S3P:892 add_points == 0) on the fused maps: the occupied beams' column form
+        s, c = O.measure(og, x, y, z, yaw, maps.reshape(-1), maps.shape[1], *beams, 0)
+        capfd.readouterr()
+        h.measure(0)
+        gs, gc = h.get_scores()
+        assert "[fuse_cols]" in capfd.readouterr().err
+        assert np.array_equal(gs, s) and np.array_equal(gc, c)
+        assert np.array_equal(h.read_map(0), maps[0])
     finally:
         h.close()
     return routes

@@ -65,6 +65,9 @@ def parse():
                          "the same collectives; about this many seconds on a fresh box, whose first process enqueues slowly)")
     ap.add_argument("--profile-steps", type=int, default=20,
                     help="steps of the second, untimed pass that times K3/K4/K5 with HIP events (0: skip)")
+    ap.add_argument("--no-fuse-kernels", action="store_true",
+                    help="skip the untimed third pass that times K2 (measure + fuse on per-particle maps) for "
+                         "roofline_other_kernels: BASELINE configs[3]'s shape and the reference's own dense beam list")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal: use the multi-GPU code path (RCCL all-gathers) even at N=1")
     return ap.parse_args()
@@ -141,6 +144,56 @@ def k1_traffic(P, M, grid):
     if (P, M, grid) != (10000, 4096, 256):
         return None
     return t["traffic_bytes_per_launch"]
+
+
+def fuse_kernels(device):
+    """K2 (measure + fuse, S3P:859-908 with add_points on) timed on per-particle maps, outside the timed
+    region, for the bench line's per-kernel rooflines: 2 B per evaluation (one byte read, one
+    written). Two beam lists: BASELINE configs[3]'s shape (50 k particles x 128^3 maps, a sparse synthetic
+    2048-beam scan: one beam per 64-byte line of a private map), and the list the reference itself fuses,
+    tests/golden/local_map_8frames_beams.npz (its local map after 8 frames: 138 710 non-zero cells in 3 945
+    columns), into 10 000 maps of its own shape, 300 x 300 x 80."""
+    from slam_amd import capi, synth
+    out = {}
+
+    def timed(h, P, M, what, reps=3):
+        h.measure(1); h.synchronize()
+        h.profile(True, [capi.PF_K_MEASURE])
+        for _ in range(reps):
+            h.measure(1)
+        h.synchronize()
+        ms, n = h.kernel_time(capi.PF_K_MEASURE)
+        h.profile(False)
+        t = ms / n * 1e-3
+        b = 2.0 * P * M
+        out[what] = {"bytes": b, "achieved": b / t / 1e9, "unit": "GB/s", "frac": b / t / 8e12, "launch_us": t * 1e6,
+                     "particles": P, "beams": M}
+
+    # configs[3]
+    P, M = 50000, 2048
+    sc = synth.scene((128, 128, 128), P, M, seed=5)
+    bx, by, bz, bv = sc["beams"]
+    bv = np.random.default_rng(1).choice(np.array([-30, -3, 10, 30, 50], np.int8), len(bx))
+    h = capi.Handle(capi.default_config(device=device, n_particles=P, grid_x=128, grid_y=128, grid_z=128,
+                                        local_x=0, local_y=0, local_z=0, max_beams=len(bx)))
+    h.broadcast_map(sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"]); h.set_beams(bx, by, bz, bv)
+    timed(h, P, len(bx), "fuse_configs3_sparse_scan")
+    h.close()
+    # the reference's own list
+    path = os.path.join(ROOT, "tests", "golden", "local_map_8frames_beams.npz")
+    if os.path.exists(path):
+        g = np.load(path)
+        beams = (g["bx"].astype(np.int32), g["by"].astype(np.int32), g["bz"].astype(np.int32), g["bv"])
+        P, M = 10000, len(beams[0])
+        rng = np.random.default_rng(2)
+        h = capi.Handle(capi.default_config(device=device, n_particles=P, max_beams=M))
+        h.broadcast_map(np.full(300 * 300 * 80, 50, np.uint8))
+        h.predict(7.5 + rng.normal(0, 0.06, P), 7.5 + rng.normal(0, 0.06, P), 1.5 + rng.normal(0, 0.03, P),
+                  0.3 + rng.normal(0, 0.05, P))
+        h.set_beams(*beams)
+        timed(h, P, M, "fuse_reference_dense_list")
+        h.close()
+    return out
 
 
 def spawn_ranks(a):
@@ -406,6 +459,11 @@ def main():
             b5 = update_traffic(sc, sensor_pos)
             other["update"] = {"bytes": b5, "achieved": b5 / (k5_ms / k5_n * 1e-3) / 1e9, "unit": "GB/s",
                                "frac": b5 / (k5_ms / k5_n * 1e-3) / 8e12}
+        if world == 1 and a.profile_steps > 0 and not a.no_fuse_kernels:
+            try:                                             # K2, untimed third pass on handles of its own
+                other.update(fuse_kernels(local_rank))
+            except Exception as e:                           # (e.g. the maps do not fit beside another job's memory)
+                other["fuse_error"] = str(e)
         out["kernel_us"] = ku
         out["roofline_other_kernels"] = other
         if world == 1 and not a.no_cpu_baseline:

@@ -44,5 +44,15 @@ for i in np.flatnonzero(slots != np.arange(P))[:4]:
 for name, kid in (("measure", capi.PF_K_MEASURE), ("weights", capi.PF_K_WEIGHTS), ("resample", capi.PF_K_RESAMPLE)):
     ms, n = h.kernel_time(kid)
     print(f"  {name}: {ms / max(n, 1):.3f} ms avg over {n}")
+# K2's roofline entry on this (sparse) scan: 2 B per evaluation, three more fused launches
+h.profile(False); h.profile(True, [capi.PF_K_MEASURE])
+for _ in range(3):
+    h.measure(1)
+h.synchronize()
+ms, n = h.kernel_time(capi.PF_K_MEASURE)
+t = ms / n * 1e-3
+print(f"K2 roofline (configs[3], sparse synthetic scan): {P} particles x {len(bx)} beams: {t * 1e3:.3f} ms per launch, "
+      f"algorithmic {2.0 * P * len(bx) / t / 1e9:.1f} GB/s = {2.0 * P * len(bx) / t / 8e12 * 100:.2f} % of 8 TB/s "
+      f"(every beam in a 64-byte line of its own in a private 2 MiB map; the reference's dense list: tools/c4_dense.py)")
 print("c4 check ok")
 h.close()

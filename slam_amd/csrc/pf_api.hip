@@ -199,6 +199,7 @@ struct pf_handle {
     char* vote_scratch = nullptr;      // pf_scan_vote's device scratch, grown on demand
     size_t vote_cap = 0;
     int32_t* bmin = nullptr;           // [ceil(P/64)] block minima of scores (pfk_reduce_scores)
+    int32_t* bmin_ext = nullptr;       // [pfk_block_minima_count(Pg)] the same for scores the caller gathered
     int32_t* draw = nullptr;           // [Pg]
     int32_t* first = nullptr;          // [Pg]
     int32_t* dup_anc = nullptr;        // [Pg]
@@ -625,7 +626,7 @@ void pf_destroy(pf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->bmin_all, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beam_blk,
+    void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->bmin_ext, h->bmin_all, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beam_blk,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
                     h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -758,6 +759,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->partial, (size_t)h->partial_rows * P));
     CREATE_TRY(dalloc(&h->scores, P));
     CREATE_TRY(dalloc(&h->bmin, (P + 63) / 64));
+    CREATE_TRY(dalloc(&h->bmin_ext, (size_t)pfk_block_minima_count((int)Pg)));
     CREATE_TRY(dalloc(&h->draw, Pg));
     CREATE_TRY(dalloc(&h->first, Pg));
     CREATE_TRY(dalloc(&h->dup_anc, Pg));
@@ -1281,7 +1283,11 @@ int pf_weights(pf_handle* h, const void* scores_global_dev) {
     {
         Timed t(h, PF_K_WEIGHTS);
         const int32_t* bmin = sc == h->scores && h->P == h->Pg ? h->bmin : gathered_bmin ? h->bmin_all : nullptr;
-        const int n_bmin = gathered_bmin ? h->comm_world * ((h->P + 63) / 64) : 0;
+        int n_bmin = gathered_bmin ? h->comm_world * ((h->P + 63) / 64) : 0;
+        if (!bmin && !h->exact && h->Pg > 4096) {     // scores from the caller's own all-gather: a pass of block minima
+            HIP_TRY(h, pfk_block_minima(h->stream, sc, h->Pg, h->bmin_ext));
+            bmin = h->bmin_ext; n_bmin = pfk_block_minima_count(h->Pg);
+        }
         const bool carry = h->upd_pending && pfk_weights_carries(h->Pg, h->exact, bmin);
         HIP_TRY(h, pfk_weights(h->stream, sc, h->Pg, h->w, h->logw, h->cdf, h->scratch, h->exact, h->first,
                                h->counters, h->rs, bmin, carry ? &h->upd : nullptr, n_bmin));

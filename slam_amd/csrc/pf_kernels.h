@@ -233,6 +233,9 @@ struct PfUpdateWork {
     PfUpdateParams up;
 };
 bool pfk_weights_carries(int Pg, bool exact, const int32_t* bmin);
+// block minima of sum_match for scores from outside (pf_weights with gathered scores): bmin[pfk_block_minima_count(Pg)]
+int pfk_block_minima_count(int Pg);
+hipError_t pfk_block_minima(hipStream_t st, const int2* scores, int Pg, int32_t* bmin);
 hipError_t pfk_update_hits(hipStream_t st, const PfUpdateWork& uw);
 hipError_t pfk_update_rays(hipStream_t st, const PfUpdateWork& uw);
 hipError_t pfk_fill_u8(hipStream_t st, uint8_t* dst, unsigned long long n, int value);

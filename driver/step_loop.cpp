@@ -16,12 +16,17 @@
 //   at the end (publish_cloud, S3P:1031-1051)
 //     pf_read_occupied
 //
-// Synthetic box room, synthetic 640x480 uint16 depth frames of it. Two handles: the filter
+// Synthetic box room with obstacles, synthetic 640x480 uint16 depth frames of it. Two handles: the filter
 // (per-particle maps, the reference's sizes) and the localisation grid (200x200x80, shared).
 //
 //   ./step_loop [steps] [particles] [truth]     (needs an MI355X; the library has no CPU path)
 //   "truth": feed the true increment as odometry instead of the scan vote (the first form of
 //   this driver; keeps the filter's input independent of the front end)
+//   ./step_loop replay <file>                   recorded inputs instead of the synthetic room and
+//   std::random_device: per frame the pooled depth image, the IMU angles and the seeds of the two
+//   index draws, per step the seed of the motion noise (the thresholds use seed + 1); prints every
+//   frame's global pose and every step's result at 17 digits. tests/test_gpu_driver.py writes such a
+//   file from tests/golden/frames.npz, the reference's own 48-frame run, and compares.
 #include "../include/slam_pf.h"
 
 #include <cmath>
@@ -46,24 +51,84 @@ std::mutex mtx;                                  // S3P:27
 const int kW = 640, kH = 480, kPool = 4;         // S3P:113-117
 const double kFocal = 385.0 / 4.0;               // S3P:124
 
-// One depth frame of a box room seen from (x, y, z, yaw) in the room's frame: the camera looks
-// along +y of its own frame (S3P:115), pixel (i, j) of the pooled image has the direction
-// (horizontal[j], 1, vertical[i]) of the reference's pinhole tables (S3P:155-162); each pooled
+// One depth frame of a box room with four box obstacles (the scene of oracle/make_golden_frontend.py, on
+// which the reference's own run tracks the truth to about 0.1 m) seen from (x, y, z, yaw) in the room's
+// frame: the camera looks along +y of its own frame (S3P:115), pixel (i, j) of the pooled image has the
+// direction (horizontal[j], 1, vertical[i]) of the reference's pinhole tables (S3P:155-162); each pooled
 // depth is written to its 4x4 block of uint16 millimetres, little-endian (S3P:587).
 void synth_depth(double x, double y, double z, double yaw, std::vector<uint8_t>& img) {
-    const double x0 = 2.0, x1 = 8.0, y0 = 2.0, y1 = 8.0, z0 = 0.8, z1 = 3.2;
+    static const double room[6] = {2.23, 7.91, 2.62, 8.37, 0.71, 3.43};            // x0 x1 y0 y1 z0 z1
+    static const double boxes[4][6] = {{6.1, 6.9, 6.4, 7.5, 0.71, 2.2}, {3.0, 3.8, 7.2, 8.37, 0.71, 1.6},
+                                       {2.23, 2.9, 4.1, 5.3, 1.2, 2.6}, {5.2, 5.6, 7.6, 7.9, 0.71, 3.43}};
     const int rh = kW / kPool, rv = kH / kPool;
+    const double o[3] = {x, y, z};
     img.assign((size_t)kW * kH * 2, 0);
     for (int i = 0; i < rv; ++i)
         for (int j = 0; j < rh; ++j) {
             const double hx = ((j + 1) - rh / 2) / kFocal, vz = -1 * ((i + 1) - rv / 2) / kFocal;
-            const double wx = std::cos(yaw) * hx - std::sin(yaw), wy = std::sin(yaw) * hx + std::cos(yaw);
+            const double d[3] = {std::cos(yaw) * hx - std::sin(yaw), std::sin(yaw) * hx + std::cos(yaw), vz};
             double t = 1e9;
-            if (wx > 0) t = std::fmin(t, (x1 - x) / wx); else if (wx < 0) t = std::fmin(t, (x0 - x) / wx);
-            if (wy > 0) t = std::fmin(t, (y1 - y) / wy); else if (wy < 0) t = std::fmin(t, (y0 - y) / wy);
-            if (vz > 0) t = std::fmin(t, (z1 - z) / vz); else if (vz < 0) t = std::fmin(t, (z0 - z) / vz);
+            for (int ax = 0; ax < 3; ++ax) {                     // the room's walls, from inside
+                if (d[ax] > 0) t = std::fmin(t, (room[2 * ax + 1] - o[ax]) / d[ax]);
+                else if (d[ax] < 0) t = std::fmin(t, (room[2 * ax] - o[ax]) / d[ax]);
+            }
+            for (const auto& bx : boxes) {                       // the obstacles, from outside (slab test)
+                double tn = -1e9, tf = 1e9;
+                for (int ax = 0; ax < 3; ++ax) {
+                    if (d[ax] == 0) { if (o[ax] < bx[2 * ax] || o[ax] > bx[2 * ax + 1]) { tn = 1e9; } continue; }
+                    const double t1 = (bx[2 * ax] - o[ax]) / d[ax], t2 = (bx[2 * ax + 1] - o[ax]) / d[ax];
+                    tn = std::fmax(tn, std::fmin(t1, t2)); tf = std::fmin(tf, std::fmax(t1, t2));
+                }
+                if (tn <= tf && tn > 0) t = std::fmin(t, tn);
+            }
             const long mm = std::lround(t * 1000.0);
-            if (mm <= 0 || mm > 6000) continue;                  // out of the sensor's range: no depth
+            if (mm < 150 || mm > 6000) continue;                 // out of the sensor's range: no depth
+            for (int a = 0; a < kPool; ++a)
+                for (int b = 0; b < kPool; ++b) {
+                    const size_t k = ((size_t)(i * kPool + a) * kW + (size_t)j * kPool + b) * 2;
+                    img[k] = (uint8_t)(mm & 0xff); img[k + 1] = (uint8_t)(mm >> 8);
+                }
+        }
+}
+// The sensor's true pose at frame f: a circle of 0.9 m radius through (5, 5) inside the room, one turn in
+// about 520 frames, the heading turning half as fast, 1.1 cm per frame.
+void truth_at(int f, double out[4]) {
+    const double ph = 0.012 * f;
+    out[0] = 5.0 + 0.9 * std::sin(ph); out[1] = 5.0 + 0.9 * (1.0 - std::cos(ph)); out[2] = 2.0; out[3] = 0.5 * ph;
+}
+struct Replay {
+    int32_t frames = 0, per_step = 0, P = 0;
+    std::vector<uint16_t> pooled;                // [frames][120][160]
+    std::vector<double> gyr;                     // [frames][3]
+    std::vector<uint32_t> seed_vote, seed_rays;  // [frames]
+    std::vector<uint32_t> step_seed;             // [frames / per_step]
+};
+bool load_replay(const char* path, Replay& r) {
+    FILE* fp = std::fopen(path, "rb");
+    if (!fp) return false;
+    bool ok = std::fread(&r.frames, 4, 1, fp) == 1 && std::fread(&r.per_step, 4, 1, fp) == 1 && std::fread(&r.P, 4, 1, fp) == 1 &&
+              r.frames > 0 && r.per_step > 0 && r.P > 0;
+    const size_t npx = (size_t)(kW / kPool) * (kH / kPool);
+    if (ok) {
+        r.pooled.resize((size_t)r.frames * npx); r.gyr.resize(3 * (size_t)r.frames);
+        r.seed_vote.resize((size_t)r.frames); r.seed_rays.resize((size_t)r.frames);
+        r.step_seed.resize((size_t)(r.frames / r.per_step));
+        ok = std::fread(r.pooled.data(), 2, r.pooled.size(), fp) == r.pooled.size() &&
+             std::fread(r.gyr.data(), 8, r.gyr.size(), fp) == r.gyr.size() &&
+             std::fread(r.seed_vote.data(), 4, r.seed_vote.size(), fp) == r.seed_vote.size() &&
+             std::fread(r.seed_rays.data(), 4, r.seed_rays.size(), fp) == r.seed_rays.size() &&
+             std::fread(r.step_seed.data(), 4, r.step_seed.size(), fp) == r.step_seed.size();
+    }
+    std::fclose(fp);
+    return ok;
+}
+// the 640 x 480 little-endian uint16 image whose 4 x 4 blocks hold the pooled depths
+void expand_pooled(const uint16_t* pooled, std::vector<uint8_t>& img) {
+    const int rh = kW / kPool, rv = kH / kPool;
+    img.assign((size_t)kW * kH * 2, 0);
+    for (int i = 0; i < rv; ++i)
+        for (int j = 0; j < rh; ++j) {
+            const unsigned mm = pooled[(size_t)i * rh + j];
             for (int a = 0; a < kPool; ++a)
                 for (int b = 0; b < kPool; ++b) {
                     const size_t k = ((size_t)(i * kPool + a) * kW + (size_t)j * kPool + b) * 2;
@@ -74,14 +139,21 @@ void synth_depth(double x, double y, double z, double yaw, std::vector<uint8_t>&
 }  // namespace
 
 int main(int argc, char** argv) {
-    const int steps = argc > 1 ? std::atoi(argv[1]) : 20;
-    const int P = argc > 2 ? std::atoi(argv[2]) : 50;
-    const bool truth_odometry = argc > 3 && std::strcmp(argv[3], "truth") == 0;
+    Replay rep;
+    const bool replay = argc > 2 && std::strcmp(argv[1], "replay") == 0;
+    if (replay && !load_replay(argv[2], rep)) {
+        std::fprintf(stderr, "cannot read the replay file %s\n", argv[2]);
+        return 1;
+    }
+    const int steps = replay ? rep.frames / rep.per_step : argc > 1 ? std::atoi(argv[1]) : 20;
+    const int P = replay ? rep.P : argc > 2 ? std::atoi(argv[2]) : 50;
+    const bool truth_odometry = !replay && argc > 3 && std::strcmp(argv[3], "truth") == 0;
 
     // ---- the filter: S3P:23-69 ----
     pf_config cfg;
     pf_default_config(&cfg);
     cfg.n_particles = cfg.n_particles_global = P;
+    cfg.max_beams = 1 << 19;                     // the local map's non-zero cells: 1.4e5 after 8 dense frames
     pf_handle* h = nullptr;
     if (pf_create(&cfg, &h) != PF_OK) {
         std::fprintf(stderr, "pf_create: %s\n", pf_last_error(nullptr));
@@ -119,33 +191,43 @@ int main(int argc, char** argv) {
     double local_pos[3] = {5, 5, 1.5}, local_yaw = 0;
     double pos[4] = {7.5, 7.5, 1.5, 0}, last_update[4] = {7.5, 7.5, 1.5, 0}, diff[4] = {0, 0, 0, 0};
     double pos_scan[3] = {5, 5, 2}, yaw_scan = 0, vote_loc[4] = {5, 5, 2, 0};
-    double gyr_yaw_old = 0, yaw_diff_scan = 0;
+    double gyr_yaw_old = 0, yaw_diff_scan = 0, rot_y = 0, rot_x = 0;   // no IMU here: rot_y = rot_x = 0 (S3P:301-302)
     int add_points = 1, best = 0;
     double truth[4] = {5, 5, 2, 0};               // the sensor in the room's frame = the localisation frame
     std::random_device rd;
     const pf_update_params upd = {10, 50, -3, -50, 3.0};   // S3P:637, 650-655, 695-700
-    const int frames_per_step = 8;
+    const int frames_per_step = replay ? rep.per_step : 8;
     long votes = 0, no_votes = 0, keyframes = 0;
 
     for (int t = 0; t < steps; ++t) {
         // ---- camera callback (S3P:168-205), `frames_per_step` depth frames ----
         for (int f = 0; f < frames_per_step; ++f) {
-            const double d[4] = {-0.012 * std::sin(truth[3]), 0.012 * std::cos(truth[3]), 0.0, 0.004};
-            for (int k = 0; k < 4; ++k) truth[k] += d[k];
-            synth_depth(truth[0], truth[1], truth[2], truth[3], img);
+            const int fno = t * frames_per_step + f;
+            double d[4] = {0, 0, 0, 0};
+            if (replay) {
+                expand_pooled(rep.pooled.data() + (size_t)fno * npix, img);
+            } else {
+                double nt[4];
+                truth_at(fno + 1, nt);
+                for (int k = 0; k < 4; ++k) { d[k] = nt[k] - truth[k]; truth[k] = nt[k]; }
+                synth_depth(truth[0], truth[1], truth[2], truth[3], img);
+            }
             int64_t n = 0;
             CK(loc, pf_depth_to_cloud(loc, img.data(), kW, kH, kPool, kFocal, cloud.data(), npix, &n));   // S3P:173-175
             double pos_diff_scan[3] = {0, 0, 0}, yaw_diff = 0;
-            const double zyx[3] = {yaw_scan, 0.0, 0.0};          // no IMU here: rot_y = rot_x = 0 (S3P:301-302)
             if (truth_odometry) {
                 pos_diff_scan[0] = std::cos(-truth[3] + d[3]) * d[0] - std::sin(-truth[3] + d[3]) * d[1];
                 pos_diff_scan[1] = std::sin(-truth[3] + d[3]) * d[0] + std::cos(-truth[3] + d[3]) * d[1];
                 pos_diff_scan[2] = d[2]; yaw_diff = d[3];
             } else if (n > 0) {
                 // scan_localization(): S3P:300-410
-                const double gyr_yaw = pos[3] + yaw_diff_scan;   // S3P:184 (no gyro message)
+                double gyr_yaw = pos[3] + yaw_diff_scan;         // S3P:184 (no gyro message)
+                if (replay) { gyr_yaw = rep.gyr[3 * (size_t)fno]; rot_y = rep.gyr[3 * (size_t)fno + 1]; rot_x = rep.gyr[3 * (size_t)fno + 2]; }
+                const double zyx[3] = {yaw_scan, rot_y, rot_x};  // S3P:301-302
                 CK(loc, pf_ring_paint(loc));                                                    // S3P:305-312
-                pfh_draw_indices(rd(), 500, (int32_t)(n - 1), pick.data());                    // S3P:315-319
+                // S3P:315-319 draws in [0, n] (one past the cloud); the driver's own seeds draw in [0, n-1],
+                // the recorded seeds were screened to stay below n
+                pfh_draw_indices(replay ? rep.seed_vote[(size_t)fno] : rd(), 500, (int32_t)(replay ? n : n - 1), pick.data());
                 for (int k = 0; k < 500; ++k)
                     for (int c = 0; c < 3; ++c) sample[3 * (size_t)k + c] = cloud[3 * (size_t)pick[(size_t)k] + c];
                 int64_t hyp = -1;
@@ -160,19 +242,21 @@ int main(int argc, char** argv) {
                 pfh_vote_epilogue(pos_scan, &yaw_scan, vote_loc, gyr_yaw, &gyr_yaw_old, pos_diff_scan,
                                   &yaw_diff_scan, &yaw_diff);                                   // S3P:379-404
                 int32_t flags = 0;
-                const double zyx_now[3] = {yaw_scan, 0.0, 0.0};
+                const double zyx_now[3] = {yaw_scan, rot_y, rot_x};
                 CK(loc, pf_ring_update(loc, cloud.data(), n, pos_scan, zyx_now, &flags));       // S3P:419-529
                 keyframes += flags & 1;
             }
             // build_local_map(): S3P:621-710
-            pfh_draw_indices(rd(), (int64_t)ray_idx.size(), (int32_t)(n > 0 ? n - 1 : 0), ray_idx.data());   // S3P:666-669
+            pfh_draw_indices(replay ? rep.seed_rays[(size_t)fno] : rd(), (int64_t)ray_idx.size(),
+                             (int32_t)(replay ? n : n > 0 ? n - 1 : 0), ray_idx.data());                  // S3P:666-669
             std::lock_guard<std::mutex> lk(mtx);                 // S3P:622
             for (int k = 0; k < 3; ++k) local_pos[k] += pos_diff_scan[k];                       // S3P:623-626
             local_yaw += yaw_diff;
-            const double lzyx[3] = {local_yaw, 0.0, 0.0};
+            const double lzyx[3] = {local_yaw, rot_y, rot_x};
             CK(h, pf_set_scan(h, cloud.data(), n, ray_idx.data(), n > 0 ? (int64_t)ray_idx.size() : 0));
             CK(h, pf_update_map(h, PF_GRID_LOCAL, &upd, local_pos, lzyx));                      // S3P:628-704
             pfh_update_realtime_pos(pos, &pos[3], pos_diff_scan, yaw_diff, diff);              // S3P:712-728
+            if (replay) std::printf("frame %d gpose %.17g %.17g %.17g %.17g\n", fno, pos[0], pos[1], pos[2], pos[3]);
         }
         // ---- particle_map() (S3P:827-962) ----
         double p_local[4], p_pos[4];
@@ -188,21 +272,22 @@ int main(int argc, char** argv) {
         }
         nb = pfh_snapshot_beams(local.data(), cfg.local_x, cfg.local_y, cfg.local_z, 100, 100, 30,
                                 bx.data(), by.data(), bz.data(), bv.data(), (int64_t)L);   // S3P:868-877
-        if (nb > cfg.max_beams) nb = cfg.max_beams;
+        if (nb > cfg.max_beams) { std::fprintf(stderr, "%lld beams beyond max_beams\n", (long long)nb); return 1; }
         CK(h, pf_set_beams(h, bx.data(), by.data(), bz.data(), bv.data(), nb));
         CK(h, pf_measure(h, add_points));                                             // S3P:859-908
-        pfh_draw_noise(rd(), P, 0.03f, 0.02f, noise.data());                          // S3P:852-855
+        pfh_draw_noise(replay ? rep.step_seed[(size_t)t] : rd(), P, 0.03f, 0.02f, noise.data());   // S3P:852-855
         pfh_predict(P, x.data(), y.data(), z.data(), yaw.data(), p_local[0] - 5, p_local[1] - 5,
                     p_local[2] - 1.5, p_local[3], noise.data());                      // S3P:911-914
         CK(h, pf_predict(h, x.data(), y.data(), z.data(), yaw.data()));
         CK(h, pf_weights(h, nullptr));                                                // S3P:920-937
         add_points = pfh_add_points_policy(p_pos, last_update, 0.4);                  // S3P:941-953
-        pfh_draw_uniform(rd(), P, u.data());                                          // S3P:768-773
+        pfh_draw_uniform(replay ? rep.step_seed[(size_t)t] + 1 : rd(), P, u.data());  // S3P:768-773
         int64_t nohit = 0, amb = 0;
         CK(h, pf_resample(h, u.data(), nullptr, slots.data(), &best, &nohit, &amb));  // S3P:954
         for (auto* v : {&x, &y, &z, &yaw}) pfh_permute(P, slots.data(), v->data(), sizeof(double));
         diff[0] = x[(size_t)best] - p_pos[0]; diff[1] = y[(size_t)best] - p_pos[1];  // S3P:956-959
         diff[2] = z[(size_t)best] - p_pos[2]; diff[3] = yaw[(size_t)best] - p_pos[3];
+        if (replay) std::printf("step %d best %d add %d feedback %.17g %.17g %.17g %.17g\n", t, best, add_points, diff[0], diff[1], diff[2], diff[3]);
         double msg_pos[3], msg_q[4];
         pfh_pose_message(pos, pos[3], msg_pos, msg_q);                                // S3P:207-222
         // the filter's frame starts at (7.5, 7.5, 1.5), the room's at (5, 5, 2)

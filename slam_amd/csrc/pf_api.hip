@@ -154,7 +154,8 @@ struct pf_handle {
     PfBeam* beams_occ = nullptr;       // [max_beams] occupied beams only (fast measure path)
     PfBeamF* beams_occ_f = nullptr;    // [max_beams] the same in fp32
     PfColG* beams_col = nullptr;       // [max_beams] the same grouped by local column (k_measure_col)
-    std::vector<PfColG> h_cols;
+    std::vector<PfColG> h_cols, h_sort_tmp;
+    std::vector<unsigned long long> h_sort_keys;
     // k_measure_box: the same groups ordered by cluster, the clusters ordered by blockIdx.y group
     PfColG* beams_colc = nullptr;      // [max_beams]
     PfCluster* clusters = nullptr;     // [max_beams]
@@ -401,12 +402,21 @@ hipError_t flush_update(pf_handle* h) {
 }
 hipError_t wait_map_writes(pf_handle* h) { return flush_update(h); }
 
-void upload_pose_rows(pf_handle* h, double* hp, const double* x, const double* y, const double* z,
-                      const double* yaw) {
+// Fills the pinned pose block; returns the index of the first particle whose pose is not finite or has
+// |pos/res| >= 2^24 (indices would no longer be exact), or -1.
+int upload_pose_rows(pf_handle* h, double* hp, const double* x, const double* y, const double* z,
+                     const double* yaw) {
     const int P = h->P;
     const double res = h->cfg.resolution;
-    auto rows = [=](int lo, int hi) {
+    const double lim = 16777216.0 * res;
+    double ysum_part[64] = {0};
+    int bad_part[64];
+    for (int& b : bad_part) b = -1;
+    auto rows = [&, hp, x, y, z, yaw, P, res, lim](int lo, int hi, int part) {
+        double ys = 0;
+        int bad = -1;
         for (int i = lo; i < hi; ++i) {
+            if (bad < 0 && (!(fabs(x[i]) < lim && fabs(y[i]) < lim && fabs(z[i]) < lim) || !isfinite(yaw[i]))) bad = i;
             hp[0 * (size_t)P + i] = x[i];
             hp[1 * (size_t)P + i] = y[i];
             hp[2 * (size_t)P + i] = z[i];
@@ -416,13 +426,14 @@ void upload_pose_rows(pf_handle* h, double* hp, const double* x, const double* y
             hp[6 * (size_t)P + i] = x[i] * 1 / res;       // S3P:862-864: a division
             hp[7 * (size_t)P + i] = y[i] * 1 / res;
             hp[8 * (size_t)P + i] = z[i] * 1 / res;
+            ys += yaw[i];
         }
+        ysum_part[part] = ys; bad_part[part] = bad;
     };
-    double ysum = 0;
-    for (int i = 0; i < P; ++i) ysum += yaw[i];
-    h->yaw_hint = ysum / P;
+    int parts_used = 1;
     // the trig is ~30 ns per particle on one core: split it over a few host threads from a few
     // thousand particles on (the same libm call per element, so the same bits)
+    bool done = false;
     if (P >= 4096) {
         if (!h->pool) {
             int n = (int)std::thread::hardware_concurrency();
@@ -435,12 +446,21 @@ void upload_pose_rows(pf_handle* h, double* hp, const double* x, const double* y
             h->pool->run_all([&](int part, int parts) {
                 const long long per = ((long long)P + parts - 1) / parts;
                 const int lo = (int)std::min<long long>(P, per * part), hi = (int)std::min<long long>(P, per * (part + 1));
-                rows(lo, hi);
+                rows(lo, hi, part);
             });
-            return;
+            parts_used = h->pool->size() + 1;
+            done = true;
         }
     }
-    rows(0, P);
+    if (!done) rows(0, P, 0);
+    double ysum = 0;
+    int bad = -1;
+    for (int k = 0; k < parts_used && k < 64; ++k) {
+        ysum += ysum_part[k];
+        if (bad_part[k] >= 0 && (bad < 0 || bad_part[k] < bad)) bad = bad_part[k];
+    }
+    h->yaw_hint = ysum / P;
+    return bad;
 }
 
 bool box_eligible(const pf_handle* h);
@@ -824,16 +844,15 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
 int pf_predict(pf_handle* h, const double* x, const double* y, const double* z, const double* yaw) {
     if (!h) return PF_ERR_ARG;
     NEED(h, x && y && z && yaw, "null pose array");
-    const double lim = 16777216.0 * h->cfg.resolution;      // |pos/res| < 2^24 keeps indices exact
-    for (int i = 0; i < h->P; ++i)
-        if (!(fabs(x[i]) < lim && fabs(y[i]) < lim && fabs(z[i]) < lim) || !isfinite(yaw[i]))
-            return fail(h, PF_ERR_ARG, "pf_predict: particle %d pose not finite or |pos/res| >= 2^24", i);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    h->pose_src = nullptr;
     const size_t nb = sizeof(double) * PF_POSE_ROWS * (size_t)h->P;
     char* slot = nullptr;
     HIP_TRY(h, h->st_pose.acquire(nb, &slot));               // pinned, double-buffered: no wait for the stream
-    upload_pose_rows(h, (double*)slot, x, y, z, yaw);
+    // (the poses are checked in the same pass that fills the block; a refused call leaves the handle's
+    // poses as they were: the block has not been committed)
+    const int bad = upload_pose_rows(h, (double*)slot, x, y, z, yaw);
+    if (bad >= 0) return fail(h, PF_ERR_ARG, "pf_predict: particle %d pose not finite or |pos/res| >= 2^24", bad);
+    h->pose_src = nullptr;
     HIP_TRY(h, hipMemcpyAsync(h->pose, slot, nb, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, h->st_pose.commit(h->stream));
     HIP_TRY(h, drop_counted_keys(h));
@@ -965,30 +984,45 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     NEED(h, n >= 0 && n <= h->cfg.max_beams, "n_beams beyond max_beams");
     NEED(h, n == 0 || (bx && by && bz && bv), "null beam array");
     h->h_beams.resize((size_t)n);
-    h->h_beams_occ.clear(); h->h_beams_occ_f.clear();
-    double lmax = 0;
-    for (int64_t j = 0; j < n; ++j) {
-        if (bx[j] < -(1 << 20) || bx[j] > (1 << 20) || by[j] < -(1 << 20) || by[j] > (1 << 20) ||
-            bz[j] < -(1 << 20) || bz[j] > (1 << 20))
-            return fail(h, PF_ERR_ARG, "pf_set_beams: beam %lld offset beyond +-2^20 voxels", (long long)j);
-        PfBeam& b = h->h_beams[(size_t)j];
-        b.lx = (double)bx[j]; b.ly = (double)by[j]; b.lz = (double)bz[j];   // S3P:745-747 int->double
-        b.v = bv[j]; b.pad = 0;
-        if (b.v > h->cfg.occ_threshold) {                                   // S3P:886
-            h->h_beams_occ.push_back(b);
-            h->h_beams_occ_f.push_back(PfBeamF{(float)bx[j], (float)by[j], (float)bz[j], 0});
-            lmax = fmax(lmax, fmax(fabs(b.lx) + fabs(b.ly), fabs(b.lz)));
+    h->h_beams_occ.resize((size_t)n + PF_BEAM_GROUP); h->h_beams_occ_f.resize((size_t)n + PF_BEAM_GROUP);
+    int n_real_occ = 0;
+    long long lmax_i = 0;
+    {
+        PfBeam* hb = h->h_beams.data();
+        PfBeam* ho = h->h_beams_occ.data();
+        PfBeamF* hf = h->h_beams_occ_f.data();
+        const int thr = h->cfg.occ_threshold;
+        for (int64_t j = 0; j < n; ++j) {
+            const int32_t X = bx[j], Y = by[j], Z = bz[j];
+            if ((uint32_t)(X + (1 << 20)) > (2u << 20) || (uint32_t)(Y + (1 << 20)) > (2u << 20) || (uint32_t)(Z + (1 << 20)) > (2u << 20))
+                return fail(h, PF_ERR_ARG, "pf_set_beams: beam %lld offset beyond +-2^20 voxels", (long long)j);
+            PfBeam b;
+            b.lx = (double)X; b.ly = (double)Y; b.lz = (double)Z;               // S3P:745-747 int->double
+            b.v = bv[j]; b.pad = 0;
+            hb[j] = b;
+            if (b.v > thr) {                                                    // S3P:886
+                ho[n_real_occ] = b;
+                hf[n_real_occ] = PfBeamF{(float)X, (float)Y, (float)Z, 0};
+                ++n_real_occ;
+                const long long r = std::max<long long>((long long)abs(X) + abs(Y), abs(Z));
+                lmax_i = std::max(lmax_i, r);
+            }
         }
     }
+    const double lmax = (double)lmax_i;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     // pad the occupied lists to a multiple of PF_BEAM_GROUP with beams no pose can bring into
     // the grid (|coordinate| ~ 2^22 voxels while |pos/res| < 2^24 ... the flat index stays far
     // outside [0, elements) for every validated pose: 2^22*gy*gz dominates)
-    const int n_real_occ = (int)h->h_beams_occ.size();
-    while (h->h_beams_occ.size() % PF_BEAM_GROUP) {
-        PfBeam d{}; d.lx = -3.0e7; d.ly = 0; d.lz = 0; d.v = 127;
-        h->h_beams_occ.push_back(d);
-        h->h_beams_occ_f.push_back(PfBeamF{-3.0e7f, 0.f, 0.f, 0});
+    {
+        size_t m = (size_t)n_real_occ;
+        while (m % PF_BEAM_GROUP) {
+            PfBeam d{}; d.lx = -3.0e7; d.ly = 0; d.lz = 0; d.v = 127;
+            h->h_beams_occ[m] = d;
+            h->h_beams_occ_f[m] = PfBeamF{-3.0e7f, 0.f, 0.f, 0};
+            ++m;
+        }
+        h->h_beams_occ.resize(m); h->h_beams_occ_f.resize(m);
     }
     const size_t no = h->h_beams_occ.size();
     // column groups: the occupied beams of one local column (a run of the list that shares (lx, ly)), lz
@@ -1004,11 +1038,17 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         for (int j = 0; j < n_real_occ;) {
             const PfBeam& b0 = h->h_beams_occ[(size_t)j];
             zs.clear(); rest.clear();
-            while (j < n_real_occ && h->h_beams_occ[(size_t)j].lx == b0.lx && h->h_beams_occ[(size_t)j].ly == b0.ly)
-                zs.push_back((int32_t)h->h_beams_occ[(size_t)j++].lz);
-            std::sort(zs.begin(), zs.end());
+            bool ascending = true;                                   // the local map's order (S3P:868): nothing to sort
+            while (j < n_real_occ && h->h_beams_occ[(size_t)j].lx == b0.lx && h->h_beams_occ[(size_t)j].ly == b0.ly) {
+                const int32_t zj = (int32_t)h->h_beams_occ[(size_t)j++].lz;
+                ascending = ascending && (zs.empty() || zj > zs.back());
+                zs.push_back(zj);
+            }
             bool distinct = true;                                    // a cell listed twice counts twice: no mask for that
-            for (size_t i = 1; i < zs.size(); ++i) distinct = distinct && zs[i] != zs[i - 1];
+            if (!ascending) {
+                std::sort(zs.begin(), zs.end());
+                for (size_t i = 1; i < zs.size(); ++i) distinct = distinct && zs[i] != zs[i - 1];
+            }
             for (size_t i = 0; i < zs.size();) {
                 size_t k = i;
                 while (k < zs.size() && zs[k] < zs[i] + 8) ++k;
@@ -1037,14 +1077,29 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     build_fuse_columns(h, n_real_occ);
     // ... and inside a phase by range: how far the lanes of a wave spread over cache lines grows
     // with the beam's range, so neighbours in this order cost about the same and go to different chunks
-    std::stable_sort(h->h_cols.begin(), h->h_cols.end(), [](const PfColG& a, const PfColG& b) {
-        if (a.n != b.n) return a.n > b.n;
-        return a.lx * a.lx + a.ly * a.ly > b.lx * b.lx + b.ly * b.ly;
-    });
+    // (sorted through 64-bit keys: count, squared range, then the position in the list)
+    auto by_range = [](std::vector<PfColG>& g, bool by_count, std::vector<unsigned long long>& keys, std::vector<PfColG>& tmp) {
+        if (g.size() >= (1u << 22)) {                              // (beyond the keys' index field: the plain way)
+            std::stable_sort(g.begin(), g.end(), [by_count](const PfColG& a, const PfColG& b) {
+                if (by_count && a.n != b.n) return a.n > b.n;
+                return a.lx * a.lx + a.ly * a.ly > b.lx * b.lx + b.ly * b.ly;
+            });
+            return;
+        }
+        keys.resize(g.size());
+        for (size_t i = 0; i < g.size(); ++i) {
+            const long long lx = (long long)g[i].lx, ly = (long long)g[i].ly;
+            const unsigned long long r2 = (unsigned long long)(lx * lx + ly * ly) >> 3;          // < 2^39
+            keys[i] = ((unsigned long long)(by_count ? 4 - g[i].n : 0) << 61) | (((1ull << 39) - 1 - r2) << 22) | (unsigned long long)i;
+        }
+        std::sort(keys.begin(), keys.end());
+        tmp.resize(g.size());
+        for (size_t i = 0; i < g.size(); ++i) tmp[i] = g[(size_t)(keys[i] & ((1ull << 22) - 1))];
+        g.swap(tmp);
+    };
+    by_range(h->h_cols, true, h->h_sort_keys, h->h_sort_tmp);
     // the run groups go in front (the longest trips first), farthest first like the others
-    std::stable_sort(runs.begin(), runs.end(), [](const PfColG& a, const PfColG& b) {
-        return a.lx * a.lx + a.ly * a.ly > b.lx * b.lx + b.ly * b.ly;
-    });
+    by_range(runs, false, h->h_sort_keys, h->h_sort_tmp);
     h->n_runs = (int)runs.size();
     h->h_cols.insert(h->h_cols.begin(), runs.begin(), runs.end());
     h->n_cols = (int)h->h_cols.size();

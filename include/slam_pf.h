@@ -128,7 +128,12 @@ int pf_read_map(pf_handle* h, int32_t i, uint8_t* dst);
  * in ascending flat order as offsets from the local origin, with their int8 value. */
 int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32_t* bz,
                  const int8_t* bv, int64_t n_beams);
-/* K1 (+K2 when add_points and PER_PARTICLE): per local particle sum_match / num_match. */
+/* K1 (+K2 when add_points and PER_PARTICLE): per local particle sum_match / num_match.
+ * Any beam list, in any order, gives the reference's results (a beam reads its cell after every earlier
+ * beam's add, S3P:886-904). The fast forms apply to lists in the local map's own order (x, y, z ascending,
+ * S3P:868): SHARED grids gather the occupied beams of a column together (8-cell z windows with four or
+ * more of them as three loads); PER_PARTICLE maps whose grid_z is a multiple of 16 walk the list as whole
+ * columns when it holds four or more beams per column, as the reference's dense local maps do. */
 int pf_measure(pf_handle* h, int add_points);
 int pf_get_scores(pf_handle* h, int32_t* sum_match, int32_t* num_match);
 /* device pointer to the local scores, int32 [n_particles][2] = (sum, count): what the caller

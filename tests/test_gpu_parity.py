@@ -925,7 +925,7 @@ def test_keyframe_ring_matches_oracle():
 @pytest.mark.parametrize("shape", [(640, 480, 4), (50, 31, 3), (64, 48, 1), (16, 16, 16)])
 def test_depth_front_end_matches_oracle(shape):
     """S3P:562-612: pooled depth image -> sensor-frame cloud, bit-exact against
-    the restatement (parity unpinned by the reference: a ROS callback). Images with holes (zero
+    the restatement (itself pinned by the reference's callback() body run here: tests/golden/depth.npz, tests/test_frontend_golden.py). Images with holes (zero
     depth), saturated pixels and fully empty pooled blocks; ragged sizes drop the remainder
     columns/rows like the reference's res_h = width/pool."""
     width, height, pool = shape

@@ -166,7 +166,7 @@ def test_200_step_run_matches_reference(golden_dir):
 
 
 def test_ring_restatement_invariants():
-    """pfo_ring_* (S3P:305-312, 419-529; parity unpinned): the life cycle of S3P:432-472 and the
+    """pfo_ring_* (S3P:305-312, 419-529; pinned by tests/golden/ring.npz in tests/test_frontend_golden.py): the life cycle of S3P:432-472 and the
     non-compacted write of S3P:454-455, on a case small enough to follow by hand."""
     dims = (20, 20, 10)
     ring = O.RingState(dims, 0.05, n_slots=3, cap=8)
@@ -220,7 +220,7 @@ def test_read_out_restatement_against_reference_index_split(golden_dir):
 
 
 def test_depth_front_end_restatement_by_hand():
-    """pfo_depth_to_cloud (S3P:562-612; parity unpinned, a ROS callback of class Slam): an 8 x 8
+    """pfo_depth_to_cloud (S3P:562-612; pinned by tests/golden/depth.npz in tests/test_frontend_golden.py): an 8 x 8
     image pooled 4 x 4 worked by hand. Block (0,0): 3 non-zero depths 1000, 2000, 2001 -> integer
     mean 1667; block (0,1): all zero -> dropped; block (1,0): one depth 65535; block (1,1): 16 x
     1500. Tables: horizontal[j] = ((j+1) - 1)/focal, vertical[i] = -((i+1) - 1)/focal."""

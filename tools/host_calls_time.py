@@ -22,4 +22,5 @@ t("predict", lambda: h.predict(x, y, z, yaw))
 t("set_beams", lambda: h.set_beams(*sc["beams"]))
 t("set_scan", lambda: h.set_scan(sc["points"], sc["ray_idx"]))
 t("set_weights", lambda: h.set_weights(u))
+t("set_best_index (binding overhead of a trivial call)", lambda: h.set_best_index(0), 2000)
 h.close()

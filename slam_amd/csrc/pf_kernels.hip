@@ -511,8 +511,10 @@ __device__ __forceinline__ void col_phase(const PfColG* __restrict__ cg, int g0,
     pp += (y - pp % C + C) % C;
     for (; 2 * pp < g1; pp += C) {
         const int ga = max(2 * pp, g0), gb = min(2 * pp + 2, g1);
+        // (a phase that starts on an odd group shares its first pair slot with the phase before it: when
+        // the phase is empty, that slot holds nothing of it)
         if (gb - ga == 2) col_trip<N, 2>(cg, ga, L, G, gp, shadow, sum, cnt);
-        else col_trip<N, 1>(cg, ga, L, G, gp, shadow, sum, cnt);
+        else if (gb - ga == 1) col_trip<N, 1>(cg, ga, L, G, gp, shadow, sum, cnt);
     }
 }
 

@@ -161,3 +161,52 @@ def test_k1_run_groups_match_oracle():
         assert len(np.unique(gc)) > 3
     finally:
         h.close()
+
+
+def test_k1_phase_that_is_empty_after_an_odd_boundary():
+    """k_measure_col deals pairs of column groups to its chunks across the phase boundaries (4-, 3-, 2-,
+    1-beam groups). With an odd number of 4-beam groups and no 3-beam group, the pair slot on the boundary
+    holds nothing of the 3-beam phase: it used to run a trip there and counted the next group twice (found
+    by tools/fuzz_fuse_cols.py). Three columns of four beams spread over z (no run group), five single
+    beams, against the oracle."""
+    from slam_amd import capi, synth
+    from oracle import binding as O
+    dims = (48, 48, 48)
+    bx, by, bz = [], [], []
+    for lx in (-3, 0, 4):
+        for lz in (-12, -2, 7, 15):
+            bx.append(lx); by.append(2); bz.append(lz)
+    for ly in range(-4, 1):
+        bx.append(6); by.append(ly); bz.append(1)
+    bx, by, bz = (np.array(a, np.int32) for a in (bx, by, bz))
+    order = np.lexsort((bz, by, bx))
+    bx, by, bz = bx[order], by[order], bz[order]
+    bv = np.full(len(bx), 50, np.int8)
+    rng = np.random.default_rng(3)
+    grid = rng.integers(0, 101, dims).astype(np.uint8)
+    P = 300
+    x = rng.uniform(1.1, 1.3, P); y = rng.uniform(1.1, 1.3, P); z = rng.uniform(1.1, 1.3, P); yaw = rng.uniform(-3.2, 3.2, P)
+    cfg = capi.default_config(n_particles=P, map_mode=capi.PF_MAP_SHARED, grid_x=dims[0], grid_y=dims[1],
+                              grid_z=dims[2], local_x=0, local_y=0, local_z=0, max_beams=len(bx))
+    h = capi.Handle(cfg)
+    try:
+        h.write_map(0, grid); h.predict(x, y, z, yaw); h.set_beams(bx, by, bz, bv)
+        h.measure(0)
+        gs, gc = h.get_scores()
+        g1 = grid.reshape(-1).copy()
+        s, c = O.measure(O.ref_grid(*dims), x, y, z, yaw, g1, 0, bx, by, bz, bv, 0)
+        assert np.array_equal(gs, s) and np.array_equal(gc, c)
+    finally:
+        h.close()
+
+
+def test_random_scenes_through_the_column_kernels():
+    """tools/fuzz_fuse_cols.py, a few dozen random scenes (grid heights 16 to 112, dense/holed/sparse/wall
+    lists, repeats and disorder, particles at the rim and on z ties, thresholds and clamps varied): the
+    column kernels with and without the add on per-particle maps and K1's run groups on the shared grid,
+    every score and map byte against the oracle. In a process of its own: it forces the column form."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_fuse_cols.py"), "40", "11"],
+                         capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stdout[-600:] + out.stderr[-300:]

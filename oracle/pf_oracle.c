@@ -1,12 +1,19 @@
 /* TEST INFRASTRUCTURE — see pf_oracle.h for status, pinning and deviations.
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared pf_oracle.c -lm  (no FMA contraction: the
  * reference is plain x86-64 g++ -O2 code, every product and sum rounds separately). */
+#define _GNU_SOURCE                                 /* sincos() */
 #include "pf_oracle.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
 #define I32_LIM 2147483648.0
+
+/* The sine and cosine of one angle, as the reference's g++ -O2 build takes them: one call of glibc's
+ * sincos(), into which g++ merges sin(a) and cos(a). Written out so that the oracle does not depend
+ * on its own optimisation level: glibc's sincos() differs from sin() and cos() in the last place for
+ * about one argument in a thousand, enough to move a ray length off a rounding tie (S3P:676). */
+#define SINCOS(a, s, c) double s, c; sincos((a), &s, &c)
 
 /* round() result -> int32 with D3: returns 0 and sets *bad when not representable. */
 static inline int32_t to_i32(double r, int* bad) {
@@ -64,7 +71,7 @@ void pfo_measure(const pfo_grid* g, int64_t P,
                  const int8_t* bv, int add_points,
                  int32_t* sum_out, int32_t* cnt_out) {
     for (int64_t i = 0; i < P; i++) {               /* S3P:859 */
-        double c = cos(yaw[i]), s = sin(yaw[i]);    /* S3P:860 */
+        SINCOS(yaw[i], s, c);                       /* S3P:860 */
         double tx = x[i] * 1 / g->resolution;       /* S3P:862-864: a division */
         double ty = y[i] * 1 / g->resolution;
         double tz = z[i] * 1 / g->resolution;
@@ -92,7 +99,7 @@ void pfo_measure(const pfo_grid* g, int64_t P,
 void pfo_voxel_indices(const pfo_grid* g, double x, double y, double z, double yaw,
                        int64_t M, const int32_t* bx, const int32_t* by, const int32_t* bz,
                        int32_t* flat_out) {
-    double c = cos(yaw), s = sin(yaw);
+    SINCOS(yaw, s, c);
     double tx = x * 1 / g->resolution, ty = y * 1 / g->resolution, tz = z * 1 / g->resolution;
     for (int64_t j = 0; j < M; j++)
         flat_out[j] = (int32_t)beam_flat(g, c, s, tx, ty, tz, bx[j], by[j], bz[j]);
@@ -101,7 +108,7 @@ void pfo_voxel_indices(const pfo_grid* g, double x, double y, double z, double y
 void pfo_predict(int64_t P, double* x, double* y, double* z, double* yaw,
                  double dlx, double dly, double dlz, double dyaw, const float* noise) {
     for (int64_t i = 0; i < P; i++) {
-        double c = cos(yaw[i]), s = sin(yaw[i]);
+        SINCOS(yaw[i], s, c);
         x[i] += c * dlx - s * dly + noise[4 * i + 0];   /* S3P:911 */
         y[i] += s * dlx + c * dly + noise[4 * i + 1];   /* S3P:912 */
         z[i] += dlz + noise[4 * i + 2];                 /* S3P:913 */
@@ -172,15 +179,16 @@ void pfo_permute(int64_t P, const int32_t* slot_anc, void* records, size_t width
 }
 
 void pfo_rot_zyx(double m[9], double z, double y, double x) {   /* S3P:536-544 */
-    m[0] = cos(y) * cos(z);
-    m[1] = cos(z) * sin(x) * sin(y) - cos(x) * sin(z);
-    m[2] = sin(x) * sin(z) + cos(x) * cos(z) * sin(y);
-    m[3] = cos(y) * sin(z);
-    m[4] = cos(x) * cos(z) + sin(x) * sin(y) * sin(z);
-    m[5] = cos(x) * sin(y) * sin(z) - cos(z) * sin(x);
-    m[6] = -sin(y);
-    m[7] = cos(y) * sin(x);
-    m[8] = cos(x) * cos(y);
+    SINCOS(z, sz, cz); SINCOS(y, sy, cy); SINCOS(x, sx, cx);
+    m[0] = cy * cz;
+    m[1] = cz * sx * sy - cx * sz;
+    m[2] = sx * sz + cx * cz * sy;
+    m[3] = cy * sz;
+    m[4] = cx * cz + sx * sy * sz;
+    m[5] = cx * sy * sz - cz * sx;
+    m[6] = -sy;
+    m[7] = cy * sx;
+    m[8] = cx * cy;
 }
 
 static inline int64_t flat_int(int32_t gy, int32_t gz, double rx, double ry, double rz,

@@ -2,6 +2,7 @@
 // HIP-only by design: there is no CPU path in this library.
 #include "../../include/slam_pf.h"
 #include "pf_kernels.h"
+#include "pf_trig.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -421,8 +422,9 @@ int upload_pose_rows(pf_handle* h, double* hp, const double* x, const double* y,
             hp[1 * (size_t)P + i] = y[i];
             hp[2 * (size_t)P + i] = z[i];
             hp[3 * (size_t)P + i] = yaw[i];
-            hp[4 * (size_t)P + i] = cos(yaw[i]);          // S3P:860 via rot_matrix (host libm)
-            hp[5 * (size_t)P + i] = sin(yaw[i]);
+            const PfSinCos t(yaw[i]);                     // S3P:860 via rot_matrix (pf_trig.h)
+            hp[4 * (size_t)P + i] = t.c;
+            hp[5 * (size_t)P + i] = t.s;
             hp[6 * (size_t)P + i] = x[i] * 1 / res;       // S3P:862-864: a division
             hp[7 * (size_t)P + i] = y[i] * 1 / res;
             hp[8 * (size_t)P + i] = z[i] * 1 / res;
@@ -543,7 +545,8 @@ void build_clusters(pf_handle* h, int n_occ) {
     if (n_occ == 0 || !box_eligible(h)) return;
     double vol = 20000, mx = 12, my = 12, mz = 6;
     if (const char* e = getenv("SLAM_PF_BOX")) (void)sscanf(e, "%lf,%lf,%lf,%lf", &vol, &mx, &my, &mz);
-    const double c0 = cos(h->yaw_hint), s0 = sin(h->yaw_hint);
+    const PfSinCos t0(h->yaw_hint);
+    const double c0 = t0.c, s0 = t0.s;
     struct Ref { float u, v, z; int idx; };
     std::vector<Ref> r((size_t)n_occ);
     for (int i = 0; i < n_occ; ++i) {
@@ -1555,15 +1558,7 @@ int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const dou
             isfinite(zyx[1]) && isfinite(zyx[2]) && fabs(pos[0]) < 1e6 && fabs(pos[1]) < 1e6 && fabs(pos[2]) < 1e6,
          "pose not finite");
     const double z = zyx[0], y = zyx[1], x = zyx[2];
-    up.rot[0] = cos(y) * cos(z);                                   // S3P:536-544, host libm
-    up.rot[1] = cos(z) * sin(x) * sin(y) - cos(x) * sin(z);
-    up.rot[2] = sin(x) * sin(z) + cos(x) * cos(z) * sin(y);
-    up.rot[3] = cos(y) * sin(z);
-    up.rot[4] = cos(x) * cos(z) + sin(x) * sin(y) * sin(z);
-    up.rot[5] = cos(x) * sin(y) * sin(z) - cos(z) * sin(x);
-    up.rot[6] = -sin(y);
-    up.rot[7] = cos(y) * sin(x);
-    up.rot[8] = cos(x) * cos(y);
+    pf_rot_zyx(up.rot, z, y, x);    // S3P:536-544
     up.pos[0] = pos[0]; up.pos[1] = pos[1]; up.pos[2] = pos[2];
     up.conv = 1 / h->cfg.resolution;                               // S3P:284
     up.max_range = p->max_range;
@@ -1604,15 +1599,7 @@ int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const dou
     for (int r = 0; r < n_yaw; ++r) {
         const double z = zyx[0] + (yaw_k0 + yaw_kstep * r) * pi / 180, y = zyx[1], x = zyx[2];   // S3P:329
         double* m = &mats[9 * (size_t)r];
-        m[0] = cos(y) * cos(z);                                   // S3P:536-544
-        m[1] = cos(z) * sin(x) * sin(y) - cos(x) * sin(z);
-        m[2] = sin(x) * sin(z) + cos(x) * cos(z) * sin(y);
-        m[3] = cos(y) * sin(z);
-        m[4] = cos(x) * cos(z) + sin(x) * sin(y) * sin(z);
-        m[5] = cos(x) * sin(y) * sin(z) - cos(z) * sin(x);
-        m[6] = -sin(y);
-        m[7] = cos(y) * sin(x);
-        m[8] = cos(x) * cos(y);
+        pf_rot_zyx(m, z, y, x);    // S3P:536-544
         int k = r * per;
         for (int a = 0; a < n_t; ++a)
             for (int b = 0; b < n_t; ++b)
@@ -1851,15 +1838,7 @@ int pf_ring_update(pf_handle* h, const double* cloud, int64_t n_points, double p
                     HIP_TRY(h, pfk_ring_set(h->stream, h->maps, slot, h->ring_count[(size_t)i], 0));
                 PfUpdateParams up{};
                 const double z = zyx[0], y = rot_y, x = rot_x;
-                up.rot[0] = cos(y) * cos(z);                                      // S3P:536-544, host libm
-                up.rot[1] = cos(z) * sin(x) * sin(y) - cos(x) * sin(z);
-                up.rot[2] = sin(x) * sin(z) + cos(x) * cos(z) * sin(y);
-                up.rot[3] = cos(y) * sin(z);
-                up.rot[4] = cos(x) * cos(z) + sin(x) * sin(y) * sin(z);
-                up.rot[5] = cos(x) * sin(y) * sin(z) - cos(z) * sin(x);
-                up.rot[6] = -sin(y);
-                up.rot[7] = cos(y) * sin(x);
-                up.rot[8] = cos(x) * cos(y);
+                pf_rot_zyx(up.rot, z, y, x);    // S3P:536-544
                 up.pos[0] = pos_scan[0]; up.pos[1] = pos_scan[1]; up.pos[2] = pos_scan[2];
                 up.conv = conv; up.elements = h->elements; up.gy = h->cfg.grid_y; up.gz = h->cfg.grid_z;
                 int32_t cnt = 0;

@@ -3,6 +3,7 @@
 // Built without FMA contraction, like the reference.
 #include "../../include/slam_pf.h"
 
+#include "pf_trig.h"
 #include <math.h>
 #include <string.h>
 #include <random>
@@ -32,7 +33,8 @@ int64_t pfh_snapshot_beams(const int8_t* local, int32_t lgx, int32_t lgy, int32_
 void pfh_predict(int64_t n, double* x, double* y, double* z, double* yaw, double dlx, double dly,
                  double dlz, double dyaw, const float* noise) {
     for (int64_t i = 0; i < n; ++i) {
-        const double c = cos(yaw[i]), s = sin(yaw[i]);
+        const PfSinCos t(yaw[i]);
+        const double c = t.c, s = t.s;
         x[i] += c * dlx - s * dly + noise[4 * i + 0];      // S3P:911
         y[i] += s * dlx + c * dly + noise[4 * i + 1];      // S3P:912
         z[i] += dlz + noise[4 * i + 2];                    // S3P:913
@@ -100,8 +102,12 @@ void pfh_vote_epilogue(double pos_scan[3], double* yaw_scan, const double loc[4]
                        double* yaw_diff_out) {
     const double pi = 2 * acos(0.0);                                          // S3P:24
     const double e0 = *yaw_scan;
-    pos_diff_out[0] = cos(-e0) * (loc[0] - pos_scan[0]) - sin(-e0) * (loc[1] - pos_scan[1]);   // S3P:379
-    pos_diff_out[1] = sin(-e0) * (loc[0] - pos_scan[0]) + cos(-e0) * (loc[1] - pos_scan[1]);   // S3P:380
+    // g++ -O2 turns cos(-a) into cos(a) and takes line 379's pair from one sincos(a); line 380's sine
+    // stays a call of sin(-a) (the store between them keeps it apart) and its cosine is reused. glibc's
+    // sin() and sincos() differ in the last place for about one argument in a thousand (pf_trig.h).
+    const PfSinCos t(e0);
+    pos_diff_out[0] = t.c * (loc[0] - pos_scan[0]) - (-t.s) * (loc[1] - pos_scan[1]);   // S3P:379
+    pos_diff_out[1] = sin(-e0) * (loc[0] - pos_scan[0]) + t.c * (loc[1] - pos_scan[1]);   // S3P:380
     pos_diff_out[2] = loc[2] - pos_scan[2];                                   // S3P:381
     const double diff_scan = loc[3] - e0;                                     // S3P:382
     *yaw_scan = loc[3];                                                       // S3P:383-386
@@ -119,8 +125,9 @@ void pfh_update_realtime_pos(double pos[3], double* yaw, const double pos_diff_s
                              double feedback[4]) {
     const double pi = 2 * acos(0.0);                                          // S3P:24
     const double e0 = *yaw;
-    pos[0] += cos(e0) * pos_diff_scan[0] - sin(e0) * pos_diff_scan[1] + feedback[0];   // S3P:713
-    pos[1] += sin(e0) * pos_diff_scan[0] + cos(e0) * pos_diff_scan[1] + feedback[1];   // S3P:714
+    const PfSinCos t(e0);
+    pos[0] += t.c * pos_diff_scan[0] - t.s * pos_diff_scan[1] + feedback[0];   // S3P:713
+    pos[1] += t.s * pos_diff_scan[0] + t.c * pos_diff_scan[1] + feedback[1];   // S3P:714
     pos[2] += pos_diff_scan[2] + feedback[2];                                 // S3P:715
     *yaw += yaw_diff + feedback[3];                                           // S3P:716
     if (*yaw > pi) *yaw += -2 * pi;                                           // S3P:717-722
@@ -130,9 +137,10 @@ void pfh_update_realtime_pos(double pos[3], double* yaw, const double pos_diff_s
 
 void pfh_pose_message(const double pos[3], double yaw, double position_out[3], double orientation_wxyz_out[4]) {
     const double pi = 2 * acos(0.0);
-    orientation_wxyz_out[0] = cos((-yaw - pi / 2) / 2);                       // S3P:212-215
+    const PfSinCos t((-yaw - pi / 2) / 2);
+    orientation_wxyz_out[0] = t.c;                                            // S3P:212-215
     orientation_wxyz_out[1] = 0;
-    orientation_wxyz_out[2] = sin((-yaw - pi / 2) / 2);
+    orientation_wxyz_out[2] = t.s;
     orientation_wxyz_out[3] = 0;
     position_out[0] = pos[0];                                                 // S3P:216-218
     position_out[1] = -pos[2];

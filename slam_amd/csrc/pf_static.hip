@@ -6,6 +6,7 @@
 // launch on the caller's stream.
 #include "../../include/slam_pf.h"
 #include "pf_kernels.h"
+#include "pf_trig.h"
 
 #include <math.h>
 #include <mutex>
@@ -94,15 +95,7 @@ extern "C" int pf_scan_vote_static(int32_t device, void* hip_stream, const uint8
     for (int r = 0; r < n_yaw; ++r) {
         const double z = zyx[0] + (yaw_k0 + yaw_kstep * r) * pi / 180, y = zyx[1], x = zyx[2];   // S3P:329
         double* m = &s.mats[9 * r];
-        m[0] = cos(y) * cos(z);                                   // S3P:536-544, host libm
-        m[1] = cos(z) * sin(x) * sin(y) - cos(x) * sin(z);
-        m[2] = sin(x) * sin(z) + cos(x) * cos(z) * sin(y);
-        m[3] = cos(y) * sin(z);
-        m[4] = cos(x) * cos(z) + sin(x) * sin(y) * sin(z);
-        m[5] = cos(x) * sin(y) * sin(z) - cos(z) * sin(x);
-        m[6] = -sin(y);
-        m[7] = cos(y) * sin(x);
-        m[8] = cos(x) * cos(y);
+        pf_rot_zyx(m, z, y, x);    // S3P:536-544
     }
     for (int k = 9 * n_yaw; k < PF_STATIC_MAX_YAW * 9; ++k) s.mats[k] = 0;
     s.pos[0] = pos[0]; s.pos[1] = pos[1]; s.pos[2] = pos[2];

@@ -194,6 +194,44 @@ def test_vote_epilogue_and_pose_message_follow_the_reference_formulas():
     assert np.array_equal(q, [np.cos(a), 0.0, np.sin(a), 0.0])
 
 
+def test_host_trig_is_the_merged_sincos_of_the_gxx_build():
+    """g++ -O2 merges the reference's sin(a) and cos(a) into glibc's sincos(a), which differs from
+    sin()/cos() in the last place for about one argument in a thousand (slam_amd/csrc/pf_trig.h); the
+    library and the oracle both take the pair from sincos(). Checked on arguments where the two
+    differ: found here with libm itself, 0.40005245828215963 among them (the yaw at which a whole-step
+    fuzz case first showed it, through a ray length on a rounding tie)."""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.cos.restype = libm.sin.restype = C.c_double
+    libm.cos.argtypes = libm.sin.argtypes = [C.c_double]
+    libm.sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rng = np.random.default_rng(3)
+    cand = np.concatenate([[0.40005245828215963], rng.uniform(-3.2, 3.2, 40000)])
+    yaws = []
+    for a in cand:
+        sv, cv = C.c_double(), C.c_double()
+        libm.sincos(float(a), C.byref(sv), C.byref(cv))
+        if sv.value != libm.sin(float(a)) or cv.value != libm.cos(float(a)):
+            yaws.append(float(a))
+    if len(yaws) < 5:
+        pytest.skip("this libm's sincos() agrees with sin() and cos(): nothing to tell apart")
+    yaw = np.array(yaws); P = len(yaw)
+    st = [np.zeros(P), np.zeros(P), np.full(P, 1.5), yaw]      # from the origin: the last place stays visible
+    s1 = [v.copy() for v in st]; s2 = [v.copy() for v in st]
+    noise = np.zeros((P, 4), np.float32)
+    capi.host_predict(*s1, (0.12, -0.07, 0.02), 0.0, noise)
+    O.predict(*s2, (0.12, -0.07, 0.02), 0.0, noise)
+    assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1])
+    plain = np.cos(yaw) * 0.12 - np.sin(yaw) * -0.07
+    assert np.any(plain != s1[0])        # the separate calls would have been visible here
+    for a in yaws[:50]:                  # pfh_update_realtime_pos: one sincos for S3P:713-714
+        sv, cv = C.c_double(), C.c_double()
+        libm.sincos(a, C.byref(sv), C.byref(cv))
+        pos, _ = capi.update_realtime_pos(np.zeros(3), a, np.array([0.3, -0.2, 0.0]), 0.0, np.zeros(4))
+        assert pos[0] == cv.value * 0.3 - sv.value * -0.2
+        assert pos[1] == sv.value * 0.3 + cv.value * -0.2
+
+
 @pytest.mark.parametrize("world,P", [(2, 50), (4, 33), (8, 125)])
 def test_migration_plan_moves_every_remote_ancestor(world, P):
     """pfh_migration_plan (S3P:805-812 across shards): each rank's send and receive lists, played

@@ -467,6 +467,39 @@ def test_update_map_shared_uint8_matches_oracle():
         h.close()
 
 
+def test_update_map_rays_on_rounding_ties():
+    """Scan points at whole numbers of half voxels from the sensor: the step count round(norm * conv)
+    (S3P:676) and the range test norm > 3 (S3P:637) then sit on ties that the last place of the rotated
+    point decides, and with it the last place of the rotation entries: the sensor yaw is one at which
+    glibc's cos() and sincos() differ (slam_amd/csrc/pf_trig.h). Found by tools/fuzz_step.py."""
+    dims = (96, 124, 80)
+    rng = np.random.default_rng(135)
+    n = 600
+    az, el = rng.uniform(-np.pi, np.pi, n), rng.uniform(-0.5, 0.5, n)
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], 1)
+    d[:200] = np.eye(3)[rng.integers(0, 3, 200)] * rng.choice([-1.0, 1.0], 200)[:, None]   # along the sensor axes too
+    k = rng.integers(4, 61, n)
+    k[::7] = 60                                                       # exactly max_range before rotation
+    pts = d * ((k + rng.choice([0.0, 0.5], n)) * 0.05)[:, None]
+    pts[::7] = d[::7] * 3.0
+    pos = np.array([2.4, 3.1, 2.0]) + rng.normal(0, 0.02, 3)
+    zyx = np.array([0.40005245828215963, 0.01, -0.02])
+    ridx = np.arange(n, dtype=np.int32)
+    prm = (10, 100, -3, 0)
+    cfg = O.UpdateCfg(dims[0], dims[1], dims[2], 0.05, 0, prm[0], prm[1], prm[2], prm[3], 3.0)
+    grid = rng.integers(0, 101, dims).astype(np.uint8)
+    want = grid.copy()
+    O.update_map(cfg, want, pos, zyx, pts, ridx)
+    h = capi.Handle(_shared_cfg(4, dims))
+    try:
+        h.write_map(0, grid)
+        h.set_scan(pts, ridx)
+        h.update_map(capi.PF_GRID_SHARED, capi.UpdateParams(*prm, 3.0), pos, zyx)
+        assert np.array_equal(h.read_map(0).reshape(dims), want)
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("world", [1, 2])
 def test_update_carried_by_the_weight_kernels_matches_oracle(world):
     """pf_update_map(PF_GRID_SHARED) only records the update; pf_weights launches it inside its own
@@ -1119,3 +1152,16 @@ def test_measure_column_groups_of_every_shape():
         assert c.min() < c.max()                            # some particles lose beams at the faces
     finally:
         h.close()
+
+
+def test_random_whole_steps_on_the_shared_grid():
+    """tools/fuzz_step.py, forty random scenes of three steps each (measure -> map update -> predict ->
+    weights -> resample; particle counts beside every block size, ragged grids, beam lists of 1 to 5000,
+    weights with zeros, one-hot and tiny): scores, weights, slots, best index, poses and the grid against
+    the oracle after every step. Its scan points sit on half-voxel ranges, so the rays' step counts are on
+    rounding ties throughout (the case that showed the sincos() difference is among these)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_step.py"), "40", "2"],
+                         capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stdout[-600:] + out.stderr[-300:]

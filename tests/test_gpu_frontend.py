@@ -112,3 +112,17 @@ def test_scan_vote_leaves_the_scan_alone(golden_dir):
         assert np.array_equal(h.read_map(0), want.reshape(-1))
     finally:
         h.close()
+
+
+def test_random_front_end_cases():
+    """tools/fuzz_front.py, fifty random cases: the scan vote with its lattice varied (1 to 16 yaws, 1 to 8
+    translations per axis) through pf_scan_vote and pf_scan_vote_static, the keyframe ring over fourteen frames
+    (slot sizes 50 to 3000, 1 to 8 slots, thresholds varied, replacements and recentrings), the depth front-end
+    at random image shapes and pools, the read-out at random strides and thresholds and the int8 local-map
+    update with every increment and clamp at the type's limits; coordinates snapped onto quarter voxels so
+    that round() sits on ties. Everything exact against the oracle."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_front.py"), "50", "3"],
+                         capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stdout[-600:] + out.stderr[-300:]

@@ -69,6 +69,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise PfError(f"{LIB_PATH} is missing: build it with `make -C slam_amd/csrc` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
+        # One HIP runtime per process: torch ships its own libamdhip64 under the same soname as
+        # /opt/rocm's, and whichever loads first serves both. With the library's first, torch later
+        # finds "No HIP GPUs"; with torch's first, both work. Python callers of this module use torch
+        # for device memory and collectives anyway, so bring it in before the library.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.pf_last_error.restype = C.c_char_p
         L.pf_last_error.argtypes = [C.c_void_p]

@@ -210,3 +210,16 @@ def test_random_scenes_through_the_column_kernels():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_fuse_cols.py"), "40", "11"],
                          capture_output=True, text=True, timeout=110)
     assert out.returncode == 0, out.stdout[-600:] + out.stderr[-300:]
+
+
+def test_random_whole_steps_on_per_particle_maps():
+    """tools/fuzz_pp.py, forty random scenes of three steps on per-particle maps (1 to 400 particles, ragged
+    grids, beam lists from a handful to a full box, increments at the int8 limits, disorder and repeats,
+    particles on quarter-voxel poses at right-angle yaws): measure with and without the fuse, weights,
+    resample with the slabs following their ancestors; every score, weight, slot, pose and map byte against
+    the oracle. The library picks its own kernels here (column form or wave per particle)."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_pp.py"), "40", "5"],
+                         capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stdout[-600:] + out.stderr[-300:]

@@ -1165,3 +1165,15 @@ def test_random_whole_steps_on_the_shared_grid():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_step.py"), "40", "2"],
                          capture_output=True, text=True, timeout=110)
     assert out.returncode == 0, out.stdout[-600:] + out.stderr[-300:]
+
+
+def test_random_sharded_jobs_equal_the_one_gpu_handle():
+    """tools/fuzz_shard.py, twenty random jobs of 2 to 8 ranks run rank after rank on this GPU (shard sizes on
+    and beside the block sizes, weights with zeros, one-hot and tiny, repeated thresholds, the map update
+    riding in every rank's weight kernels, two steps in a row): scores, pose blocks, weights, slots, best
+    index, counters, poses and the grid of every rank against the one-GPU handle, bit for bit."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_shard.py"), "20", "4"],
+                         capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stdout[-600:] + out.stderr[-300:]

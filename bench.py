@@ -133,6 +133,67 @@ def cpu_baseline(sc, dims, P, M, seconds):
                       f"{dims[0]}^3 grid) in {el:.1f} s, 1 thread, gcc -O2"}
 
 
+def reference_own_case(seconds):
+    """The reference itself beside the port: its particle_map() (S3P:827-962, the g++ -O2 build of its own
+    text that oracle/build_ref.sh makes, oracle/_ref/libs3p_ref.so) timed on this host at its own sizes,
+    the only ones it compiles for: 50 particles with a 300x300x80 map each, the local map an 8-frame
+    snapshot of 138 710 non-zero cells (tests/golden/local_map_8frames_beams.npz). One thread, as the
+    reference runs it (S3P:1107). None when the build is not in the tree."""
+    import ctypes as C
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, "oracle", "_ref", "libs3p_ref.so")
+    fx = os.path.join(here, "tests", "golden", "local_map_8frames_beams.npz")
+    if not (os.path.exists(so) and os.path.exists(fx)):
+        return None
+    r = C.CDLL(so)
+    r.ref_map_local_ptr.restype = C.POINTER(C.c_int8)
+    r.ref_set_particle.argtypes = [C.c_int] + [C.c_double] * 5
+    r.ref_set_local_pose.argtypes = [C.c_double] * 4
+    r.ref_set_global_pose.argtypes = [C.c_double] * 4
+    r.ref_set_policy.argtypes = [C.c_int] + [C.c_double] * 4 + [C.c_int]
+    b = np.load(fx)
+    LX, LY, LZ = 200, 200, 80
+    local = np.zeros((LX, LY, LZ), np.int8)
+    local[b["bx"].astype(int) + 100, b["by"].astype(int) + 100, b["bz"].astype(int) + 30] = b["bv"]   # S3P:875-877
+    n_beams = int(np.count_nonzero(local))
+    P = 50
+    r.ref_alloc_particles(P); r.ref_init_maps()
+    rng = np.random.default_rng(1)
+    for i in range(P):
+        r.ref_set_particle(i, 7.5 + rng.normal(0, 0.03), 7.5 + rng.normal(0, 0.03), 1.5, rng.normal(0, 0.02), 1.0 / P)
+    dst = np.ctypeslib.as_array(r.ref_map_local_ptr(), shape=(LX * LY * LZ,))
+    buf = C.create_string_buffer(1 << 16)
+    out = {}
+    for add in (0, 1):
+        reps, el = 0, 0.0
+        while el < seconds / 2 and reps < 200:
+            dst[:] = local.reshape(-1)                              # the call empties map_local (S3P:840)
+            r.ref_set_local_pose(5.0, 5.0, 1.5, 0.0); r.ref_set_global_pose(7.5, 7.5, 1.5, 0.0)
+            r.ref_set_policy(add, 7.5, 7.5, 1.5, 0.0, 0)
+            r.ref_set_seed(100 + reps)
+            t0 = time.perf_counter()
+            r.ref_particle_map(buf, len(buf))
+            el += time.perf_counter() - t0
+            reps += 1
+        out[add] = (reps * P * n_beams / el, reps, el)
+    # the port on the same case (measure loop only: the reference's call also predicts, weighs and resamples
+    # its 50 particles, which is noise beside 7 million evaluations)
+    from oracle import binding as O
+    g = O.ref_grid(300, 300, 80)
+    maps = np.full((P, 300 * 300 * 80), 50, np.uint8)
+    rng = np.random.default_rng(1)
+    px = np.array([7.5 + rng.normal(0, 0.03) for _ in range(P)]); py = px[::-1].copy()
+    beams = (b["bx"].astype(np.int32), b["by"].astype(np.int32), b["bz"].astype(np.int32), b["bv"])
+    t0 = time.perf_counter()
+    O.measure(g, px, py, np.full(P, 1.5), np.zeros(P), maps.reshape(-1), maps.shape[1], *beams, 0)
+    port = P * len(beams[0]) / (time.perf_counter() - t0)
+    return {"value": out[0][0], "unit": "evals/s", "cores": 1, "kind": "reference",
+            "with_map_fuse_value": out[1][0], "port_same_case_value": port,
+            "sample": f"the reference's own particle_map() at its own sizes (50 particles x {n_beams} beams, per-particle "
+                      f"300x300x80 maps): {out[0][1]} calls without the map fuse in {out[0][2]:.1f} s, {out[1][1]} with it in "
+                      f"{out[1][2]:.1f} s; g++ -O2, 1 thread"}
+
+
 def k1_traffic(P, M, grid):
     """HBM-side bytes per K1 launch from the committed PMC passes (profiles/r2_k1_traffic.json,
     made by tools/pmc_k1.sh), or None when this run is not the workload they were taken on."""
@@ -468,6 +529,12 @@ def main():
         out["roofline_other_kernels"] = other
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, dims, P, M, a.cpu_seconds)
+            try:
+                own = reference_own_case(min(a.cpu_seconds, 8.0))
+            except Exception as e:                            # a baseline beside the baseline: never fatal
+                own = {"error": f"{type(e).__name__}: {e}"}
+            if own:
+                out["cpu_baseline"]["reference_own_case"] = own
         print(json.dumps(out), flush=True)
     h.close()
     if sharded:

@@ -322,6 +322,78 @@ def gen_local_map(r, rng):
     np.savez_compressed(os.path.join(OUT, "local_map.npz"), **cases)
 
 
+def gen_local_map_ties(r):
+    """build_local_map() where its roundings sit on ties (own RNG: the other fixtures do not move). Scan
+    points at odd multiples of 25 mm from the sensor along directions with integer components (3-4-5,
+    7-24-25, 12-16-15, 9-12-20 and the axes), so that round(norm * 20) (S3P:676) is on a tie in exact
+    arithmetic, and at exactly 3 m for the range test (S3P:637); the local yaws are angles at which glibc's
+    sincos() -- which g++ -O2 makes of the reference's sin() and cos() calls -- differs from the separate
+    calls in the last place. What decides each tie is then the last place of the rotated point."""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.cos.restype = libm.sin.restype = C.c_double
+    libm.cos.argtypes = libm.sin.argtypes = [C.c_double]
+    libm.sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rng = np.random.default_rng(7700)
+    yaws = [0.40005245828215963]
+    while len(yaws) < 4:
+        a = float(rng.uniform(-3.1, 3.1))
+        sv, cv = C.c_double(), C.c_double()
+        libm.sincos(a, C.byref(sv), C.byref(cv))
+        if cv.value != libm.cos(a) and sv.value != libm.sin(a):
+            yaws.append(a)
+    dirs = []
+    for t in ((1, 0, 0), (3, 4, 0), (7, 24, 0), (12, 16, 15), (9, 12, 20)):
+        q = np.array(t) * (25 // int(round(np.sqrt(sum(v * v for v in t)))))      # |q| = 25 (mm)
+        for perm in ((0, 1, 2), (1, 0, 2), (2, 1, 0), (0, 2, 1), (1, 2, 0), (2, 0, 1)):
+            for sg in ((1, 1, 1), (-1, 1, 1), (1, -1, 1), (1, 1, -1), (-1, -1, 1), (-1, 1, -1), (1, -1, -1), (-1, -1, -1)):
+                dirs.append(q[list(perm)] * np.array(sg))
+    dirs = np.unique(np.array(dirs), axis=0)
+    cases = {}
+    for k, yaw in enumerate(yaws):
+        r.ref_slam_reset()
+        n = 4000
+        m = rng.integers(2, 70, n) * 2 + 1                       # odd: the step count is on a tie
+        m[::9] = 120                                             # exactly 3 m: the range test is
+        m[1::9] = rng.integers(2, 70, len(m[1::9])) * 2          # even: whole steps, the plain case
+        cloud = (dirs[rng.integers(0, len(dirs), n)] * m[:, None]) / 1000.0
+        pre = np.zeros(NL, np.int8)
+        if k % 2:
+            pre[:] = pre_map(k)
+        local_pose = np.array([5.0 + 0.025 * int(rng.integers(-8, 9)), 5.0 + 0.025 * int(rng.integers(-8, 9)), 1.5, yaw])
+        if k >= 2:
+            local_pose[:3] += rng.uniform(-0.2, 0.2, 3)
+        diffs = np.zeros(4)
+        rot_y, rot_x = (0.0, 0.0) if k < 3 else (0.013, -0.021)
+        gpose = np.array([7.5, 7.5, 1.5, yaw])
+        fb = np.zeros(4)
+        local_grid(r)[:] = pre
+        r.ref_set_cloud(vp(cloud), n)
+        r.ref_set_local_pose(*[float(v) for v in local_pose])
+        r.ref_set_global_pose(*[float(v) for v in gpose])
+        r.ref_set_feedback(*[float(v) for v in fb])
+        r.ref_set_diffs(*[float(v) for v in diffs])
+        r.ref_set_rot_yx(float(rot_y), float(rot_x))
+        seed, rays = screened_seed(r, 52000 + 13 * k, 2400, n)
+        r.ref_set_seed(seed)
+        r.ref_build_local_map()
+        post = local_grid(r).copy()
+        touched = np.flatnonzero(post != pre).astype(np.int32)
+        lp = dvec(r, "ref_get_local_pose", 4); gp = dvec(r, "ref_get_global_pose", 4)
+        fb_after = dvec(r, "ref_get_feedback", 4)
+        name = f"t{k}_ties"
+        cases[name + "_cloud_mm"] = mm16(cloud)
+        cases[name + "_pre_k"] = np.int64(k if pre.any() else -1)
+        cases[name + "_local_pose"] = local_pose; cases[name + "_diffs"] = diffs
+        cases[name + "_rot_yx"] = np.array([rot_y, rot_x]); cases[name + "_gpose"] = gpose; cases[name + "_fb"] = fb
+        cases[name + "_seed"] = np.int64(seed); cases[name + "_rays"] = rays
+        cases[name + "_touched"] = touched; cases[name + "_touched_val"] = post[touched]
+        cases[name + "_map_crc"] = crc(post)
+        cases[name + "_local_pose_after"] = lp; cases[name + "_gpose_after"] = gp; cases[name + "_fb_after"] = fb_after
+        print(f"local_map_ties {name}: yaw={yaw!r} touched={len(touched)}")
+    np.savez_compressed(os.path.join(OUT, "local_map_ties.npz"), **cases)
+
+
 def gen_ring(r, rng):
     """scan_localization_map_update() alone (S3P:419-529), poses set by the harness: keyframes whose
     points partly leave the grid (the non-compacted write of S3P:454-455), slot expiry, and
@@ -457,6 +529,9 @@ def main():
         sys.exit("oracle/_ref/libs3p_ref.so missing: run oracle/build_ref.sh (needs /root/reference)")
     os.makedirs(OUT, exist_ok=True)
     r = load_ref()
+    if len(sys.argv) > 1 and sys.argv[1] == "ties":         # the later addition, on its own: nothing else is rewritten
+        gen_local_map_ties(r)
+        return
     rng = np.random.default_rng(20261112)
     gen_helpers_p(r, rng)
     gen_depth(r, rng)
@@ -464,6 +539,7 @@ def main():
     gen_local_map(r, rng)
     gen_ring(r, rng)
     gen_frames(r, rng)
+    gen_local_map_ties(r)
     print("front-end fixtures written to", OUT)
 
 

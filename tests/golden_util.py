@@ -73,10 +73,10 @@ def check_vote_cases(golden_dir, make_loc):
 
 
 # ---- build_local_map(): local_map.npz ---------------------------------------------------------
-def check_local_map_cases(golden_dir, make_mapper):
-    g = load(golden_dir, "local_map.npz")
+def check_local_map_cases(golden_dir, make_mapper, fixture="local_map.npz", at_least=5):
+    g = load(golden_dir, fixture)
     names = case_names(g, "_seed")
-    assert len(names) >= 5
+    assert len(names) >= at_least
     for name in names:
         mapper = make_mapper()
         pre = pre_map(int(g[name + "_pre_k"]))

@@ -44,6 +44,15 @@ def test_local_map_update_matches_reference(golden_dir):
     G.check_local_map_cases(golden_dir, OracleMapper)
 
 
+def test_local_map_update_on_rounding_ties_matches_reference(golden_dir):
+    """build_local_map() of the reference where its roundings sit on ties (tests/golden/local_map_ties.npz,
+    made by `oracle/make_golden_frontend.py ties` from the reference's own class Slam): scan points at odd
+    multiples of 25 mm along integer directions, at exactly 3 m, local yaws at which glibc's sincos() -- what
+    g++ -O2 makes of the reference's sin() and cos() -- differs from the separate calls in the last place.
+    Pins the choice of slam_amd/csrc/pf_trig.h to the reference build itself."""
+    G.check_local_map_cases(golden_dir, OracleMapper, "local_map_ties.npz", 4)
+
+
 def test_keyframe_ring_matches_reference(golden_dir):
     G.check_ring_calls(golden_dir, OracleLocHandle())
 

@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-update", action="store_true", help="leave K5 out of the step")
     ap.add_argument("--time-all-kernels", action="store_true",
                     help="HIP events around K3/K4/K5 too (kernel_us); costs host time in the step")
+    ap.add_argument("--watchdog-seconds", type=float, default=480.0,
+                    help="several ranks only: end the job with exit code 124 if it has not finished by then (0: never)")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="sharded runs: all-gathers through torch.distributed instead of the library's own RCCL calls")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -309,6 +311,19 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+        if world > 1 and a.watchdog_seconds > 0:
+            # a job of several ranks that stops making progress (a collective one rank never enters) would
+            # otherwise sit there until whoever launched it gives up: end it with a message instead
+            import threading
+
+            def give_up():
+                sys.stderr.write(f"bench.py: rank {rank} of {world} did not finish within {a.watchdog_seconds:.0f} s "
+                                 "(a collective that never returned?): giving up\n")
+                sys.stderr.flush()
+                os._exit(124)
+            wd = threading.Timer(a.watchdog_seconds, give_up)
+            wd.daemon = True
+            wd.start()
 
     P, M, dims = a.particles, a.beams, (a.grid, a.grid, a.grid)
     Pg = P * world

@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-update", action="store_true", help="leave K5 out of the step")
     ap.add_argument("--time-all-kernels", action="store_true",
                     help="HIP events around K3/K4/K5 too (kernel_us); costs host time in the step")
+    ap.add_argument("--no-exchange-check", action="store_true",
+                    help="several ranks: skip the start-up comparison of the in-library exchange with torch.distributed")
     ap.add_argument("--watchdog-seconds", type=float, default=480.0,
                     help="several ranks only: end the job with exit code 124 if it has not finished by then (0: never)")
     ap.add_argument("--torch-collectives", action="store_true",
@@ -194,6 +196,35 @@ def reference_own_case(seconds):
             "sample": f"the reference's own particle_map() at its own sizes (50 particles x {n_beams} beams, per-particle "
                       f"300x300x80 maps): {out[0][1]} calls without the map fuse in {out[0][2]:.1f} s, {out[1][1]} with it in "
                       f"{out[1][2]:.1f} s; g++ -O2, 1 thread"}
+
+
+def exchange_self_check(capi, ShardedBackend, dist, cfg, sc, Pg, stream):
+    """One step (measure, weights, resample) on two fresh handles of this rank, one exchanging through the
+    library's RCCL group and one through torch.distributed: weights, slots, best index and poses must be the
+    same bits. Returns True when they are."""
+    outs = []
+    u = capi.draw_uniform(77, Pg)
+    for native in (True, False):
+        h = capi.Handle(cfg)
+        try:
+            h.set_stream(stream.cuda_stream)
+            b = ShardedBackend(h, dist, native=native)
+            if native and not b.native:
+                return False
+            h.write_map(0, sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+            h.set_weights(np.full(Pg, 1.0 / Pg)); h.set_beams(*sc["beams"])
+            b.measure(0)
+            h.predict(sc["x"] + 0.01, sc["y"] - 0.01, sc["z"], sc["yaw"] + 0.005)
+            b.weights()
+            w_pre, _ = h.get_weights()
+            slots, best, nohit, amb = b.resample(u)
+            w_post, _ = h.get_weights()
+            outs.append((w_pre, np.asarray(slots), int(best), int(nohit), w_post, np.stack(h.get_poses())))
+        finally:
+            h.close()
+    a0, a1 = outs
+    return (np.array_equal(a0[0], a1[0]) and np.array_equal(a0[1], a1[1]) and a0[2:4] == a1[2:4]
+            and np.array_equal(a0[4], a1[4]) and np.array_equal(a0[5], a1[5]))
 
 
 def k1_traffic(P, M, grid):
@@ -348,6 +379,24 @@ def main():
         torch.cuda.set_stream(work_stream)
         h.set_stream(work_stream.cuda_stream)
     be = ShardedBackend(h, dist, native=not a.torch_collectives) if sharded else h
+    collectives_note = None
+    if sharded and be.native and not a.no_exchange_check:
+        # The library's own RCCL exchange has only ever run on one rank before a job like this one: check one
+        # whole step of it against the same step through torch.distributed (two handles, same inputs) before
+        # anything is timed, and use the torch exchange if the two differ or the library's fails.
+        ok = 1
+        try:
+            ok = int(exchange_self_check(capi, ShardedBackend, dist, cfg, sc, Pg, work_stream))
+        except Exception as e:                                # a failed call, not a hang (the watchdog has those)
+            sys.stderr.write(f"bench.py: rank {rank}: exchange self-check raised {type(e).__name__}: {e}\n")
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            be = ShardedBackend(h, dist, native=False)
+            collectives_note = "torch.distributed (the in-library exchange failed its start-up check against it)"
+        else:
+            collectives_note = "in-library RCCL group (start-up check against torch.distributed: identical)"
     h.write_map(0, sc["grid"])
     h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
     h.set_weights(np.full(Pg, 1.0 / Pg))
@@ -499,7 +548,7 @@ def main():
                                    + ("" if a.no_update else "+update_map(all beams cast)"),
                        "particles_per_gpu": P, "particles_total": Pg, "beams": M,
                        "grid": list(dims), "order": "fast" if Pg > 2048 else "exact",
-                       "collectives": ("rccl in-library" if getattr(be, "native", False) else "torch.distributed nccl") if sharded else "none",
+                       "collectives": (collectives_note or ("rccl in-library" if getattr(be, "native", False) else "torch.distributed nccl")) if sharded else "none",
                        "thresholds": "resident" if a.resident_thresholds else "new every step (S3P:769), staged in pinned memory",
                        "inputs": "host memory every step (pf_set_beams, pf_set_scan, pf_predict, thresholds)"
                                  if a.host_inclusive else "resident in HBM",

@@ -240,6 +240,43 @@ def k1_traffic(P, M, grid):
     return t["traffic_bytes_per_launch"]
 
 
+def k1_l2_hit(P, M, grid):
+    """L2 (TCC) hit rate of K1 from the same committed PMC passes, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r2_k1_traffic.json")) as f:
+            t = json.load(f)
+    except OSError:
+        return None
+    return t.get("l2_hit_rate") if (P, M, grid) == (10000, 4096, 256) else None
+
+
+def stream_copy_gbps(device, mib=1024, reps=10):
+    """What this box's HBM does on a plain device-to-device copy (bytes read + bytes written per second):
+    the measured figure SURVEY 8d asks for beside the 8 TB/s the roofline is quoted against."""
+    import torch
+    a = torch.empty(mib << 20, dtype=torch.uint8, device=device); b = torch.empty_like(a)
+    b.copy_(a); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record(); torch.cuda.synchronize()
+    return 2.0 * reps * (mib << 20) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def host_cpu():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    return {"model": model, "cpus_online": os.cpu_count(),
+            "cpus_this_job_may_use": int(os.environ.get("OMP_NUM_THREADS", "0")) or None}
+
+
 def fuse_kernels(device):
     """K2 (measure + fuse, S3P:859-908 with add_points on) timed on per-particle maps, outside the timed
     region, for the bench line's per-kernel rooflines: 2 B per evaluation (one byte read, one
@@ -558,7 +595,9 @@ def main():
                        "ambiguous_draws": int(amb_total), "nohit_draws": int(nohit_total)},
             "roofline": {"bound": "hbm", "kernel": "k_measure_col", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": k1_traffic(P, M, a.grid), "algorithmic_bytes_per_launch": k1_bytes,
+                         "traffic": k1_traffic(P, M, a.grid), "l2_hit_rate": k1_l2_hit(P, M, a.grid),
+                         "measured_stream_copy": stream_copy_gbps(f"cuda:{local_rank}"),
+                         "algorithmic_bytes_per_launch": k1_bytes,
                          "avg_launch_us": k1_avg_s * 1e6, "launches": int(k1_n),
                          "k1_evals_per_s": P * M / k1_avg_s if k1_avg_s > 0 else 0.0},
         }
@@ -599,6 +638,7 @@ def main():
                 own = {"error": f"{type(e).__name__}: {e}"}
             if own:
                 out["cpu_baseline"]["reference_own_case"] = own
+            out["cpu_baseline"]["host"] = host_cpu()
         print(json.dumps(out), flush=True)
     h.close()
     if sharded:

@@ -1403,7 +1403,8 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
         // weight from the division, all of partial sums <= cdf[k]: the two differ by at most
         // (k + 52) * 2^-53 * cdf[k] * (1 + 1e-9). k_search takes that with 12 % to spare as the band
         // of boundary k (`bound` = the unit roundoff with the factor); it decides how often a step
-        // pays for the sequential-order CDF: about once per 1/(8e-17 Pg^3) steps.
+        // pays for the sequential-order CDF: about once per 1/(8e-17 Pg^3) steps, and half as often since
+        // draw_is_ambiguous tests a draw inside that band again with the partial sums bounded block by block.
         // resample() on its own (S3P:757-821 on the weights pf_set_weights put there): the CDF is
         // built in the reference's sequential order, so no draw is ambiguous
         const bool alone = !h->weighted;

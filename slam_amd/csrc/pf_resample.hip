@@ -812,6 +812,29 @@ __device__ inline int search_draw(const double* __restrict__ cdf, double ui, int
     pos = lo;
     return hit ? lo - 1 : i;
 }
+// Is the draw ui, found in the interval (cdf[lo-1], cdf[lo]) of the parallel CDF, too close to one of the
+// two boundaries for the parallel and the sequential CDF to be sure to agree on it? `bound` is the unit
+// roundoff with its safety factor (pf_api.hip). The sequential sum s_k = fl(s_(k-1) + w_k) differs from the
+// exact one by sum_j d_j (s_(j-1) + w_j) with |d_j| <= 2^-53, i.e. by at most 2^-53 times the sum of its own
+// partial sums; the parallel one by ~50 roundings of sums <= cdf[k]; the weights' division adds one each.
+// First the cheap form of that (every partial sum <= cdf[k]: k * cdf[k]); a draw inside that band, about one
+// in a million, is tested again with the partial sums bounded block by block (the 256 of block q by the CDF at
+// the block's end): half the band on an even CDF, and half as many steps that pay for the sequential CDF.
+// (bound < 0: the cheap form only, SLAM_PF_LOOSE_BAND=1, for comparing how often the two forms flag a step)
+__device__ inline bool draw_is_ambiguous(double ui, int lo, const double* cdf, int Pg, double bound) {
+    const bool loose_only = bound < 0.0;
+    bound = fabs(bound);
+    const double c = cdf[lo], below = ui - cdf[lo - 1], above = c - ui;
+    const double extra = 64.0 + (double)(Pg >> 16);
+    const double loose = bound * ((double)lo + extra) * c;
+    if (!(below <= loose || above <= loose)) return false;
+    if (loose_only) return true;
+    const int b = (lo - 1) / NB;                            // block of boundary lo: indices b*NB+1 .. (b+1)*NB
+    double ends = 0.0;
+    for (int q = 0; q < b; ++q) ends += cdf[(q + 1) * NB];
+    const double band = bound * ((double)NB * ends + ((double)(lo - b * NB) + extra) * c);
+    return below <= band || above <= band;
+}
 // What follows the bisection for draw i with threshold ui: lo = first j in [1, Pg] with
 // cdf[j] > ui, Pg + 1 when there is none.
 __device__ inline void d_search_tail(int i, double ui, int lo, const double* cdf, int Pg, double bound,
@@ -819,14 +842,7 @@ __device__ inline void d_search_tail(int i, double ui, int lo, const double* cdf
     const bool hit = lo <= Pg && cdf[lo - 1] < ui;
     draw[i] = hit ? lo - 1 : i;
     if (!hit) atomicAdd(&counters[0], 1ull);
-    if (bound > 0.0) {
-        bool amb = !hit;
-        // |parallel - sequential| at boundary k <= (k + ~50) roundings of sums <= cdf[k]
-        // (pf_api.hip); `bound` is the unit roundoff with its safety factor
-        const double band = hit ? bound * ((double)lo + 64.0 + (double)(Pg >> 16)) * cdf[lo] : 0.0;
-        if (hit) amb = (ui - cdf[lo - 1] <= band) || (cdf[lo] - ui <= band);
-        if (amb) atomicAdd(&counters[1], 1ull);
-    }
+    if (bound != 0.0 && (!hit || draw_is_ambiguous(ui, lo, cdf, Pg, bound))) atomicAdd(&counters[1], 1ull);
 }
 // The same search in two levels: the CDF at the end of every 256-particle block staged in LDS
 // (XTOP entries at most), bisected there, then the eight probes inside the block that holds the
@@ -869,14 +885,7 @@ __device__ inline void d_search(int i, const double* cdf, const double* __restri
     bool hit; int lo;
     draw[i] = search_draw(cdf, ui, i, Pg, hit, lo);
     if (!hit) atomicAdd(&counters[0], 1ull);
-    if (bound > 0.0) {
-        bool amb = !hit;
-        // |parallel - sequential| at boundary k <= (k + ~50) roundings of sums <= cdf[k]
-        // (pf_api.hip); `bound` is the unit roundoff with its safety factor
-        const double band = hit ? bound * ((double)lo + 64.0 + (double)(Pg >> 16)) * cdf[lo] : 0.0;
-        if (hit) amb = (ui - cdf[lo - 1] <= band) || (cdf[lo] - ui <= band);
-        if (amb) atomicAdd(&counters[1], 1ull);
-    }
+    if (bound != 0.0 && (!hit || draw_is_ambiguous(ui, lo, cdf, Pg, bound))) atomicAdd(&counters[1], 1ull);
 }
 __global__ __launch_bounds__(NB) void k_search(const double* __restrict__ cdf,
                                                const double* __restrict__ u, int Pg, double bound,
@@ -1389,10 +1398,12 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
         return hipGetLastError();
     }
     const bool folded = nb <= WG && !chain_only();
+    static const bool loose_band = getenv("SLAM_PF_LOOSE_BAND") && atoi(getenv("SLAM_PF_LOOSE_BAND")) != 0;
+    const double sb = loose_band ? -bound : bound;          // (development knob: the first, cheaper band alone)
     if (nb <= XTOP && !chain_only())
-        hipLaunchKernelGGL(k_search_t, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, bound, draw, counters);
+        hipLaunchKernelGGL(k_search_t, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, sb, draw, counters);
     else
-        hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, bound, draw, counters);
+        hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, sb, draw, counters);
     // draws that sit within the parallel CDF's rounding error of a boundary are settled on the
     // sequential-order CDF of the same weights (nothing happens when there are none). Such a draw
     // turns up about once in 1/(8e-17 Pg^3) steps: up to PF_FOLD_CDF_MAX particles that is rare

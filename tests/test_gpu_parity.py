@@ -334,6 +334,38 @@ def test_boundary_draws_at_large_counts_match_the_sequential_loop(P):
         h.close()
 
 
+def test_draws_between_the_two_ambiguity_bands():
+    """K4's band around a CDF boundary (FAST order): a draw inside the first, cheap band (k + 64 roundings of
+    sums <= cdf[k]) is tested again with the sequential sum's error bounded through its partial sums block by
+    block (draw_is_ambiguous, about half the band on an even CDF). Draws at three quarters of the first band
+    from a boundary must no longer send the step to the sequential-order CDF, draws at a quarter of it still
+    must, and either way the resampled slots are the ones the oracle's sequential loop draws."""
+    P, M, dims = 50000, 64, (32, 32, 32)
+    sc = synth.scene(dims, P, M, seed=9)
+    rng = np.random.default_rng(P + 1)
+    w0 = rng.random(P) + 0.5; w0 /= w0.sum()
+    for frac, flagged in ((0.75, False), (0.25, True)):
+        h = capi.Handle(_shared_cfg(P, dims, order_mode=capi.PF_ORDER_FAST))
+        try:
+            h.write_map(0, sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+            h.set_weights(w0); h.set_beams(*sc["beams"]); h.measure(0); h.weights()
+            gw, _ = h.get_weights()
+            cdf = np.concatenate([[0.0], np.cumsum(gw)])                   # cdf[k] = sum of the first k weights
+            bound = 1.125 * 2.0 ** -53
+            u = capi.draw_uniform(6, P)
+            k1 = np.arange(P // 2, P // 2 + 1000); k2 = np.arange(P - 3000, P - 2000)
+            loose = lambda k: bound * (k + 1 + 64.0) * cdf[k + 1]          # the band of the interval above boundary k
+            u[:1000] = cdf[k1] + frac * loose(k1)                          # above boundary k1: lands in interval k1 + 1
+            u[1000:2000] = cdf[k2] - frac * bound * (k2 + 64.0) * cdf[k2]  # below boundary k2: in interval k2
+            assert np.all(u[:1000] < cdf[k1 + 1]) and np.all(u[1000:2000] > cdf[k2 - 1])
+            d, sa, best, nohit = O.resample(gw.copy(), u, 0)
+            slots, gbest, gnohit, amb = h.resample(u)
+            assert np.array_equal(slots, sa) and gbest == best and gnohit == nohit
+            assert (amb >= 2000) if flagged else (amb <= 3), (frac, amb)
+        finally:
+            h.close()
+
+
 def test_systematic_thresholds_same_kernel():
     """north_star's systematic resampling = the same kernels fed (u0+i)/N."""
     P, M, dims = 3000, 512, (64, 64, 64)

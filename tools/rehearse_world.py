@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--particles", type=int, default=10000)
     ap.add_argument("--beams", type=int, default=4096)
     ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--fresh", type=int, default=0, help="cycle through this many pre-drawn threshold sets (0: the same thresholds every step)")
     a = ap.parse_args()
     import torch
     from slam_amd import capi, synth
@@ -87,17 +88,20 @@ def main():
     for _ in range(a.warmup):
         h.resample(None, enqueue(), False)
     h.synchronize(); torch.cuda.synchronize()
+    sets = [capi.draw_uniform(900 + k, Pg) for k in range(a.fresh)]
+    amb_steps = amb_total = 0
     t0 = time.perf_counter()
     for i in range(a.steps):
-        h.resample_async(None, enqueue(), False)
+        h.resample_async(sets[i % a.fresh] if a.fresh else None, enqueue(), False)
         if i:
-            h.resample_result()
-    h.resample_result()
+            r = h.resample_result(); amb_steps += r[-1] > 0; amb_total += r[-1]
+    r = h.resample_result(); amb_steps += r[-1] > 0; amb_total += r[-1]
     h.synchronize(); torch.cuda.synchronize()
     el = time.perf_counter() - t0
     print(json.dumps({"world_rehearsed": W, "particles_local": P, "particles_global": Pg, "beams": M,
                       "ms_per_step": el / a.steps * 1e3,
                       "evals_per_s_per_rank": P * M * a.steps / el,
+                      "steps": a.steps, "steps_with_ambiguous_draws": int(amb_steps), "ambiguous_draws": int(amb_total),
                       "note": "one rank's compute, collectives replaced by device copies"}), flush=True)
     h.close()
 

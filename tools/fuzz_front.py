@@ -46,35 +46,42 @@ def cloud_for(rng, grid_occ, dims, pos, zyx, n, res=0.05):
     return snap(rng, pts)
 
 
-def shared(dims, max_points):
+def shared(dims, max_points, res=0.05):
     return capi.Handle(capi.default_config(n_particles=1, map_mode=capi.PF_MAP_SHARED, grid_x=dims[0], grid_y=dims[1],
-                                           grid_z=dims[2], local_x=0, local_y=0, local_z=0, max_beams=16, max_points=max(max_points, 1)))
+                                           grid_z=dims[2], local_x=0, local_y=0, local_z=0, max_beams=16, max_points=max(max_points, 1),
+                                           resolution=res))
+
+
+def pick_res(rng):
+    """FUZZ_RES=1: voxel sizes other than the reference's 0.05 m as well"""
+    return float(rng.choice([0.05, 0.1, 0.04, 0.025])) if os.environ.get("FUZZ_RES") else 0.05
 
 
 def one_vote(rng, why):
     dims = tuple(int(v) for v in rng.integers(20, 140, 3))
     grid = (rng.random(dims) < rng.choice([0.02, 0.2, 0.6])).astype(np.uint8)
     n = int(rng.choice([0, 1, 2, 63, 64, 65, 255, 257, 500, 1000, 4096]))
-    pos = snap(rng, np.array(dims) * 0.05 * rng.uniform(0.2, 0.8, 3))
+    res = pick_res(rng)
+    pos = snap(rng, np.array(dims) * res * rng.uniform(0.2, 0.8, 3))
     zyx = np.array([rng.uniform(-3.2, 3.2), rng.normal(0, 0.03), rng.normal(0, 0.03)])
     if rng.random() < 0.3:
         zyx[:] = [rng.choice([0.0, 0.40005245828215963, np.pi / 2, -np.pi]), 0.0, 0.0]
-    pts = cloud_for(rng, np.argwhere(grid > 0), dims, pos, zyx, n)
+    pts = cloud_for(rng, np.argwhere(grid > 0), dims, pos, zyx, n, res)
     kw = dict(n_yaw=int(rng.choice([1, 3, 5, 7, 16])), yaw_k0=int(rng.integers(-8, 3)), yaw_kstep=int(rng.integers(0, 5)),
               n_t=int(rng.choice([1, 2, 5, 6, 8])), length=float(rng.choice([0.25, 0.05, 0.4, 0.3])))
-    want, wbest = O.scan_vote(grid, 0.05, pts, pos, zyx, **kw)
-    h = shared(dims, n)
+    want, wbest = O.scan_vote(grid, res, pts, pos, zyx, **kw)
+    h = shared(dims, n, res)
     try:
         h.write_map(0, grid.reshape(-1))
         got, gbest = h.scan_vote(pts, pos, zyx, **kw)
         note("votes"); note("votes with a winner", wbest >= 0); note("vote counts", int(want.sum()))
         if not (np.array_equal(got, want) and gbest == wbest):
-            why.append(f"vote dims={dims} n={n} {kw}: {int((got != want).sum())} sums differ, best {gbest}/{wbest}")
+            why.append(f"vote dims={dims} n={n} res={res} {kw}: {int((got != want).sum())} sums differ, best {gbest}/{wbest}")
         if n <= 4096 and kw["n_yaw"] <= 16 and kw["n_t"] <= 8:
             g = torch.tensor(grid.reshape(-1), device="cuda"); p = torch.tensor(np.ascontiguousarray(pts).reshape(-1), device="cuda")
             s = torch.zeros(kw["n_yaw"] * kw["n_t"] ** 3, dtype=torch.int32, device="cuda")
             torch.cuda.synchronize()
-            capi.scan_vote_static(0, 0, g.data_ptr(), dims, 0.05, p.data_ptr() if n else 0, n, pos, zyx, s.data_ptr(), **kw)
+            capi.scan_vote_static(0, 0, g.data_ptr(), dims, res, p.data_ptr() if n else 0, n, pos, zyx, s.data_ptr(), **kw)
             torch.cuda.synchronize()
             if not np.array_equal(s.cpu().numpy(), want):
                 why.append(f"vote_static dims={dims} n={n} {kw}: {int((s.cpu().numpy() != want).sum())} sums differ")
@@ -174,10 +181,11 @@ def one_readout(rng, why):
 def one_local_update(rng, why):
     dims = tuple(int(v) for v in rng.integers(20, 150, 3))
     n = int(rng.choice([1, 5, 64, 500, 3000])); r = int(rng.choice([0, 1, 100, 2400]))
-    pos = snap(rng, np.array(dims) * 0.05 * rng.uniform(0.2, 0.8, 3), 0.3)
+    res = pick_res(rng)
+    pos = snap(rng, np.array(dims) * res * rng.uniform(0.2, 0.8, 3), 0.3)
     zyx = np.array([rng.uniform(-3.2, 3.2), rng.normal(0, 0.03), rng.normal(0, 0.03)])
     d = rng.normal(0, 1, (n, 3)); d /= np.linalg.norm(d, axis=1)[:, None]
-    rngs = rng.integers(1, 140, n) * 0.025                         # to 3.5 m, on half-voxel steps
+    rngs = rng.integers(1, 140, n) * (res / 2)                     # on half-voxel steps (to 3.5 m at 0.05 m)
     pts = d * rngs[:, None]
     axis = rng.random(n) < 0.3
     pts[axis] = (np.eye(3)[rng.integers(0, 3, n)] * rngs[:, None])[axis]
@@ -185,17 +193,17 @@ def one_local_update(rng, why):
     prm = (int(rng.choice([10, 1, 127])), int(rng.choice([50, 127, 0])), int(rng.choice([-3, -1, -127])), int(rng.choice([-50, -128, 0])))
     mr = float(rng.choice([3.0, 1.0, 100.0]))
     grid = rng.integers(-128, 128, dims).astype(np.int8) if rng.random() < 0.5 else np.zeros(dims, np.int8)
-    cfg = O.UpdateCfg(dims[0], dims[1], dims[2], 0.05, 1, prm[0], prm[1], prm[2], prm[3], mr)
+    cfg = O.UpdateCfg(dims[0], dims[1], dims[2], res, 1, prm[0], prm[1], prm[2], prm[3], mr)
     want = grid.copy(); O.update_map(cfg, want, pos, zyx, pts, ridx)
     h = capi.Handle(capi.default_config(n_particles=1, grid_x=8, grid_y=8, grid_z=8, local_x=dims[0], local_y=dims[1], local_z=dims[2],
-                                        max_beams=16, max_points=max(n, r, 1)))
+                                        max_beams=16, max_points=max(n, r, 1), resolution=res))
     try:
         h.write_local_map(grid); h.set_scan(pts, ridx)
         h.update_map(capi.PF_GRID_LOCAL, capi.UpdateParams(*prm, mr), pos, zyx)
         got = h.read_local_map().reshape(dims)
         note("local updates"); note("local cells changed", int((want != grid).sum()))
         if not np.array_equal(got, want):
-            why.append(f"local update dims={dims} n={n} r={r} prm={prm} range={mr}: {int((got != want).sum())} cells")
+            why.append(f"local update dims={dims} n={n} r={r} prm={prm} range={mr} res={res}: {int((got != want).sum())} cells")
     finally:
         h.close()
 

@@ -5,7 +5,7 @@ counts on and beside every block size the kernels use, grids whose sizes are not
 beam lists from one beam to thousands, weights with zeros, one-hot and tiny values, thresholds that repeat.
 Scores, resampled slots, best index and the grid are compared exactly; weights exactly in the exact order
 (up to 2048 particles) and to 1e-12 beyond (the fixed-shape sums differ from the sequential ones by rounding).
-    python tools/fuzz_step.py [cases] [seed]"""
+    python tools/fuzz_step.py [cases] [seed]        (FUZZ_RES=1: voxel sizes 0.025 to 0.1 m and occupancy thresholds 0 to 99 as well)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,7 +27,9 @@ for case in range(cases):
     if rng.random() < 0.4:
         dims = tuple(int(v) // 4 * 4 for v in dims)
     M = int(rng.choice([1, 2, 3, 5, 31, 33, 100, 500, 2000, 5000]))
-    sc = synth.scene(dims, P, M, seed=case, max_range_vox=int(0.6 * max(dims)))
+    res = float(rng.choice([0.05, 0.05, 0.1, 0.04, 0.025])) if os.environ.get("FUZZ_RES") else 0.05
+    thr = int(rng.choice([20, 20, 0, 49, 99])) if os.environ.get("FUZZ_RES") else 20
+    sc = synth.scene(dims, P, M, resolution=res, seed=case, max_range_vox=int(0.6 * max(dims)))
     beams_all = sc["beams"]
     if len(beams_all[0]) == 0:
         continue
@@ -41,11 +43,12 @@ for case in range(cases):
         w = w / w.sum()
     grid = sc["grid"].copy()
     x, y, z, yaw = sc["x"].copy(), sc["y"].copy(), sc["z"].copy(), sc["yaw"].copy()
-    og = O.ref_grid(*dims)
+    og = O.ref_grid(*dims, resolution=res, occ_threshold=thr)
     prm = (10, 100, -3, 0)
-    ucfg = O.UpdateCfg(dims[0], dims[1], dims[2], 0.05, 0, prm[0], prm[1], prm[2], prm[3], 3.0)
+    ucfg = O.UpdateCfg(dims[0], dims[1], dims[2], res, 0, prm[0], prm[1], prm[2], prm[3], 3.0)
     cfg = capi.default_config(n_particles=P, map_mode=capi.PF_MAP_SHARED, grid_x=dims[0], grid_y=dims[1], grid_z=dims[2],
-                              local_x=0, local_y=0, local_z=0, max_beams=len(beams_all[0]), max_points=max(len(sc["points"]), 1))
+                              local_x=0, local_y=0, local_z=0, max_beams=len(beams_all[0]), max_points=max(len(sc["points"]), 1),
+                              resolution=res, occ_threshold=thr)
     h = capi.Handle(cfg)
     why = []
     best = 0
@@ -58,7 +61,7 @@ for case in range(cases):
             s, c = O.measure(og, x, y, z, yaw, grid.reshape(-1), 0, *beams, 0)
             gs, gc = h.get_scores()
             if not (np.array_equal(gs, s) and np.array_equal(gc, c)):
-                why.append(f"step {step} scores: {int(((gs != s) | (gc != c)).sum())} particles"); break
+                why.append(f"step {step} scores (res {res} thr {thr}): {int(((gs != s) | (gc != c)).sum())} particles"); break
             if len(sc["points"]) and rng.random() < 0.8:
                 pos = sc["true_pose"][:3] + rng.normal(0, 0.05, 3); zyx = np.array([sc["true_pose"][3] + rng.normal(0, 0.05), 0.01, -0.02])
                 pts = sc["points"]; ridx = np.arange(len(pts), dtype=np.int32)

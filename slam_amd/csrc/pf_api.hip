@@ -740,7 +740,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->pose, PF_POSE_ROWS * P));
     CREATE_TRY(dalloc(&h->w, Pg));
     CREATE_TRY(dalloc(&h->logw, Pg));
-    CREATE_TRY(dalloc(&h->cdf, Pg + 1));
+    CREATE_TRY(dalloc(&h->cdf, Pg + 1 + (Pg + 255) / 256));   // + the CDF at the end of every 256-particle block (k_search_t's table)
     CREATE_TRY(dalloc(&h->scratch, Pg + 1));
     CREATE_TRY(dalloc(&h->u, Pg));
     const unsigned long long map_bytes =
@@ -1421,7 +1421,8 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
                                 h->pose, h->pose_src, (const double*)poses_global_dev, h->slab ? h->maps : nullptr,
                                 h->slab, (unsigned long long)h->elements, h->draw, h->first, h->dup_anc,
                                 h->free_slot, h->slot_anc, h->best, h->counters, h->rs, h->d_result + h->result_slot_u64 * slot,
-                                count_keys ? h->order_hist[0] : nullptr, h->order_keys, op));
+                                count_keys ? h->order_hist[0] : nullptr, h->order_keys, op,
+                                h->weighted && !h->exact));   // the FAST-order weight kernels left the block-end table behind the CDF
         h->hist_counted = count_keys;
         h->pose_src = nullptr;                        // every row is in h->pose now
     }

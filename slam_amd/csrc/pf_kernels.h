@@ -157,7 +157,8 @@ struct PfResampleScratch {
 };
 
 struct PfUpdateWork;
-// K3: S3P:920-937. w in/out [Pg]; logw out [Pg]; cdf out [Pg+1]; scratch double [Pg+1].
+// K3: S3P:920-937. w in/out [Pg]; logw out [Pg]; cdf out [Pg+1] (the FAST-order kernels also leave the CDF at
+// the end of every 256-particle block in cdf[Pg+1 .. Pg+1+ceil(Pg/256)) for K4's search); scratch double [Pg+1].
 // Also initialises K4's first[Pg] table and counters[0..2] for this step.
 // bmin (may be null): n_bmin (0: ceil(Pg/64)) block minima of exactly these scores, as
 // pfk_reduce_scores writes them (gathered rank by rank on a sharded handle); saves the min pass.
@@ -191,7 +192,7 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
                         int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
                         unsigned long long* counters, PfResampleScratch sc,
                         unsigned long long* host_out, int32_t* order_hist, int32_t* order_keys,
-                        PfOrderParams op);
+                        PfOrderParams op, bool tops_valid = false);
 
 #define PF_RESULT_HEADER 4
 #define PF_RESULT_BLOCKS (1ull << 63)

@@ -670,7 +670,9 @@ __device__ inline void d3_norm_v(int vb, int lt, double* sh4, int Pg, double raw
     if (g < Pg) {
         w[g] = raw / S;                                     // S3P:936
         logw[g] = (float)(lb - prm[PRM_LSE]);
-        cdf[g + 1] = (boff_vb + (woff + inc)) / S;
+        const double cv = (boff_vb + (woff + inc)) / S;
+        cdf[g + 1] = cv;
+        if (lt == NB - 1 || g == Pg - 1) cdf[Pg + 1 + vb] = cv;   // the block's end once more, contiguous (k_search_t)
         first[g] = NEVER_DRAWN;                             // K4's first-occurrence table
     }
     if (g == 0) cdf[0] = 0;
@@ -821,7 +823,10 @@ __device__ inline int search_draw(const double* __restrict__ cdf, double ui, int
 // in a million, is tested again with the partial sums bounded block by block (the 256 of block q by the CDF at
 // the block's end): half the band on an even CDF, and half as many steps that pay for the sequential CDF.
 // (bound < 0: the cheap form only, SLAM_PF_LOOSE_BAND=1, for comparing how often the two forms flag a step)
-__device__ inline bool draw_is_ambiguous(double ui, int lo, const double* cdf, int Pg, double bound) {
+// (top: the block ends staged in LDS when the caller has them, top[q] == cdf[(q + 1) * NB]; a lane that walks
+// thousands of them in global memory holds its whole workgroup up for hundreds of microseconds)
+__device__ inline bool draw_is_ambiguous(double ui, int lo, const double* cdf, int Pg, double bound,
+                                         const double* top = nullptr) {
     const bool loose_only = bound < 0.0;
     bound = fabs(bound);
     const double c = cdf[lo], below = ui - cdf[lo - 1], above = c - ui;
@@ -831,18 +836,19 @@ __device__ inline bool draw_is_ambiguous(double ui, int lo, const double* cdf, i
     if (loose_only) return true;
     const int b = (lo - 1) / NB;                            // block of boundary lo: indices b*NB+1 .. (b+1)*NB
     double ends = 0.0;
-    for (int q = 0; q < b; ++q) ends += cdf[(q + 1) * NB];
+    if (top) { for (int q = 0; q < b; ++q) ends += top[q]; }
+    else { for (int q = 0; q < b; ++q) ends += cdf[(q + 1) * NB]; }
     const double band = bound * ((double)NB * ends + ((double)(lo - b * NB) + extra) * c);
     return below <= band || above <= band;
 }
 // What follows the bisection for draw i with threshold ui: lo = first j in [1, Pg] with
 // cdf[j] > ui, Pg + 1 when there is none.
 __device__ inline void d_search_tail(int i, double ui, int lo, const double* cdf, int Pg, double bound,
-                                     int32_t* draw, unsigned long long* counters) {
+                                     int32_t* draw, unsigned long long* counters, const double* top = nullptr) {
     const bool hit = lo <= Pg && cdf[lo - 1] < ui;
     draw[i] = hit ? lo - 1 : i;
     if (!hit) atomicAdd(&counters[0], 1ull);
-    if (bound != 0.0 && (!hit || draw_is_ambiguous(ui, lo, cdf, Pg, bound))) atomicAdd(&counters[1], 1ull);
+    if (bound != 0.0 && (!hit || draw_is_ambiguous(ui, lo, cdf, Pg, bound, top))) atomicAdd(&counters[1], 1ull);
 }
 // The same search in two levels: the CDF at the end of every 256-particle block staged in LDS
 // (XTOP entries at most), bisected there, then the eight probes inside the block that holds the
@@ -851,15 +857,17 @@ __device__ inline void d_search_tail(int i, double ui, int lo, const double* cdf
 // ambiguity band and searched again on the sequential-order CDF anyway. The probes that cost a
 // round trip to L2 drop from ~10 of 14 (10 k particles) or 13 of 17 (80 k) to four.
 #define XTOP 4096
+// (use_tops: the weight kernels left those block ends behind the CDF, cdf[Pg+1+j]: one coalesced read per
+// workgroup instead of nb loads 2 KB apart, which at a million particles was 0.6 ms of this kernel)
 __global__ __launch_bounds__(NB) void k_search_t(const double* __restrict__ cdf,
                                                  const double* __restrict__ u, int Pg, double bound,
                                                  int32_t* __restrict__ draw,
-                                                 unsigned long long* counters) {
+                                                 unsigned long long* counters, int use_tops) {
     __shared__ double top[XTOP];
     const int nb = (Pg + NB - 1) / NB;                       // <= XTOP (pfk_resample)
     const int i = blockIdx.x * NB + threadIdx.x;
     const double ui = i < Pg ? u[i] : 0.0;
-    for (int j = threadIdx.x; j < nb; j += NB) top[j] = cdf[min((j + 1) * NB, Pg)];
+    for (int j = threadIdx.x; j < nb; j += NB) top[j] = use_tops ? cdf[Pg + 1 + j] : cdf[min((j + 1) * NB, Pg)];
     __syncthreads();
     if (i >= Pg) return;
     int lo = 0, hi = nb;                                    // first block whose last boundary is above ui
@@ -876,7 +884,7 @@ __global__ __launch_bounds__(NB) void k_search_t(const double* __restrict__ cdf,
         }
         pos = a;
     }
-    d_search_tail(i, ui, pos, cdf, Pg, bound, draw, counters);
+    d_search_tail(i, ui, pos, cdf, Pg, bound, draw, counters, top);
 }
 __device__ inline void d_search(int i, const double* cdf, const double* __restrict__ u, int Pg,
                                 double bound, int32_t* draw, unsigned long long* counters) {
@@ -1385,7 +1393,7 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
                         int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
                         unsigned long long* counters, PfResampleScratch sc,
                         unsigned long long* host_out, int32_t* order_hist, int32_t* order_keys,
-                        PfOrderParams op) {
+                        PfOrderParams op, bool tops_valid) {
     const int nb = nblocks(Pg);
     // counters[0..2] and first[] were initialised by the weight kernels of this step
     if (!pose_src) pose_src = pose;
@@ -1401,7 +1409,7 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
     static const bool loose_band = getenv("SLAM_PF_LOOSE_BAND") && atoi(getenv("SLAM_PF_LOOSE_BAND")) != 0;
     const double sb = loose_band ? -bound : bound;          // (development knob: the first, cheaper band alone)
     if (nb <= XTOP && !chain_only())
-        hipLaunchKernelGGL(k_search_t, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, sb, draw, counters);
+        hipLaunchKernelGGL(k_search_t, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, sb, draw, counters, tops_valid ? 1 : 0);
     else
         hipLaunchKernelGGL(k_search, dim3(nb), dim3(NB), 0, st, cdf, u, Pg, sb, draw, counters);
     // draws that sit within the parallel CDF's rounding error of a boundary are settled on the

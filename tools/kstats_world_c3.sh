@@ -4,6 +4,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 w=$1
+rm -rf gpurun_out/kc3_$w
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kc3_$w -- python3 tools/rehearse_world.py --world $w --particles 125000 --beams 16384 --steps 40 --warmup 5 --fresh 4 > gpurun_out/kc3_$w.log 2>&1 || { tail -3 gpurun_out/kc3_$w.log; exit 1; }
 f=$(find gpurun_out/kc3_$w -name '*kernel_stats.csv' | head -1)
 python3 - "$f" <<'PY'

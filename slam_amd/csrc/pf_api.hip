@@ -14,6 +14,7 @@
 #include <new>
 #include <string>
 #include <algorithm>
+#include <atomic>
 #include <vector>
 #include <condition_variable>
 #include <functional>
@@ -74,7 +75,7 @@ struct Stage {
 class HostPool {
 public:
     explicit HostPool(int n) {
-        for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { run(i); });
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { run(); });
     }
     ~HostPool() {
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
@@ -82,38 +83,56 @@ public:
         for (auto& t : workers_) t.join();
     }
     int size() const { return (int)workers_.size(); }
-    // fn(part, parts) on every worker and on the caller (part == parts - 1); returns when all are done
-    void run_all(const std::function<void(int, int)>& fn) {
-        const int parts = size() + 1;
-        { std::lock_guard<std::mutex> lk(mu_); fn_ = &fn; pending_ = size(); ++gen_; }
+    // fn(chunk) for chunk = 0 .. nchunks-1, each exactly once, by the caller and by whichever workers are awake in
+    // time; returns when every chunk is done. Chunks are claimed from a counter, so the call does not wait for a
+    // worker that wakes late (waking fifteen threads on one mutex takes longer than the work at 10 k particles):
+    // such a worker finds nothing left to claim. A job lives in a shared object, so a late worker never touches
+    // the next job's counter with this job's function.
+    void run_chunks(int nchunks, const std::function<void(int)>& fn) {
+        auto job = std::make_shared<Job>();
+        job->fn = &fn; job->nchunks = nchunks;
+        { std::lock_guard<std::mutex> lk(mu_); job_ = job; ++gen_; }
         cv_.notify_all();
-        fn(parts - 1, parts);
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [this] { return pending_ == 0; });
-        fn_ = nullptr;
+        work(*job);
+        // (the last chunks may still be running on workers: they are short)
+        for (int spin = 0; job->done.load(std::memory_order_acquire) < nchunks; ++spin) {
+            if (spin < 2000) __builtin_ia32_pause(); else std::this_thread::yield();
+        }
+        { std::lock_guard<std::mutex> lk(mu_); if (job_ == job) job_.reset(); }
     }
 private:
-    void run(int i) {
+    struct Job {
+        const std::function<void(int)>* fn = nullptr;     // valid until done == nchunks (the caller waits for that)
+        int nchunks = 0;
+        std::atomic<int> next{0}, done{0};
+    };
+    static void work(Job& j) {
+        for (;;) {
+            const int c = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (c >= j.nchunks) return;
+            (*j.fn)(c);
+            j.done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void run() {
         unsigned long long seen = 0;
         for (;;) {
-            const std::function<void(int, int)>* fn;
+            std::shared_ptr<Job> job;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return gen_ != seen; });
                 seen = gen_;
                 if (stop_) return;
-                fn = fn_;
+                job = job_;
             }
-            (*fn)(i, size() + 1);
-            { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_.notify_one(); }
+            if (job) work(*job);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex mu_;
-    std::condition_variable cv_, done_;
-    const std::function<void(int, int)>* fn_ = nullptr;
+    std::condition_variable cv_;
+    std::shared_ptr<Job> job_;
     unsigned long long gen_ = 0;
-    int pending_ = 0;
     bool stop_ = false;
 };
 
@@ -237,6 +256,9 @@ struct pf_handle {
     double* points = nullptr;          // [max_points][3]
     double* wpts = nullptr;            // [max_points][3]
     int32_t* ray_idx = nullptr;        // [max_points]
+    bool full_list_resident = true, occ_lists_resident = true;   // false: still in h_beams / h_beams_occ(_f) only
+    std::vector<double> h_ysum;        // pf_predict's per-chunk yaw sums and first bad indices
+    std::vector<int> h_badc;
     // host staging
     Stage st_pose, st_beams, st_weights, st_scan;   // pinned, double-buffered (pf_predict, pf_set_beams, ...)
     std::unique_ptr<HostPool> pool;                 // host threads for pf_predict's trig (created on first use)
@@ -410,10 +432,12 @@ int upload_pose_rows(pf_handle* h, double* hp, const double* x, const double* y,
     const int P = h->P;
     const double res = h->cfg.resolution;
     const double lim = 16777216.0 * res;
-    double ysum_part[64] = {0};
-    int bad_part[64];
-    for (int& b : bad_part) b = -1;
-    auto rows = [&, hp, x, y, z, yaw, P, res, lim](int lo, int hi, int part) {
+    // chunks of 512 particles; the yaw sums are kept per chunk and added in chunk order (the same mean whoever ran what)
+    const int CH = 512, nch = (P + CH - 1) / CH;
+    std::vector<double>& ysum_c = h->h_ysum; ysum_c.assign((size_t)nch, 0.0);
+    std::vector<int>& bad_c = h->h_badc; bad_c.assign((size_t)nch, -1);
+    auto rows = [&, hp, x, y, z, yaw, P, res, lim](int c) {
+        const int lo = c * CH, hi = std::min(P, lo + CH);
         double ys = 0;
         int bad = -1;
         for (int i = lo; i < hi; ++i) {
@@ -430,9 +454,8 @@ int upload_pose_rows(pf_handle* h, double* hp, const double* x, const double* y,
             hp[8 * (size_t)P + i] = z[i] * 1 / res;
             ys += yaw[i];
         }
-        ysum_part[part] = ys; bad_part[part] = bad;
+        ysum_c[(size_t)c] = ys; bad_c[(size_t)c] = bad;
     };
-    int parts_used = 1;
     // the trig is ~30 ns per particle on one core: split it over a few host threads from a few
     // thousand particles on (the same libm call per element, so the same bits)
     bool done = false;
@@ -445,21 +468,16 @@ int upload_pose_rows(pf_handle* h, double* hp, const double* x, const double* y,
             h->pool.reset(new HostPool(n));
         }
         if (h->pool->size() > 0) {
-            h->pool->run_all([&](int part, int parts) {
-                const long long per = ((long long)P + parts - 1) / parts;
-                const int lo = (int)std::min<long long>(P, per * part), hi = (int)std::min<long long>(P, per * (part + 1));
-                rows(lo, hi, part);
-            });
-            parts_used = h->pool->size() + 1;
+            h->pool->run_chunks(nch, rows);
             done = true;
         }
     }
-    if (!done) rows(0, P, 0);
+    if (!done) for (int c = 0; c < nch; ++c) rows(c);
     double ysum = 0;
     int bad = -1;
-    for (int k = 0; k < parts_used && k < 64; ++k) {
-        ysum += ysum_part[k];
-        if (bad_part[k] >= 0 && (bad < 0 || bad_part[k] < bad)) bad = bad_part[k];
+    for (int c = 0; c < nch; ++c) {
+        ysum += ysum_c[(size_t)c];
+        if (bad < 0 && bad_c[(size_t)c] >= 0) bad = bad_c[(size_t)c];
     }
     h->yaw_hint = ysum / P;
     return bad;
@@ -651,7 +669,7 @@ void pf_destroy(pf_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->bmin_ext, h->bmin_all, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beam_blk,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
-                    h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_idx};
+                    h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : h->ev) for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -822,9 +840,10 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(dalloc(&h->order_hist[1], (size_t)PF_ORDER_BUCKETS));
     CREATE_TRY(hipMemsetAsync(h->order_hist[0], 0, sizeof(int32_t) * PF_ORDER_BUCKETS, h->stream));
     CREATE_TRY(hipMemsetAsync(h->order_hist[1], 0, sizeof(int32_t) * PF_ORDER_BUCKETS, h->stream));
-    CREATE_TRY(dalloc(&h->points, 3 * (size_t)c.max_points));
+    // the scan's points and, behind them (256-byte aligned, placed by pf_set_scan), its ray indices: one block, one copy
+    CREATE_TRY(dalloc(&h->points, 3 * (size_t)c.max_points + ((size_t)c.max_points + 1) / 2 + 64));
     CREATE_TRY(dalloc(&h->wpts, 3 * (size_t)c.max_points));
-    CREATE_TRY(dalloc(&h->ray_idx, (size_t)c.max_points));
+    h->ray_idx = (int32_t*)h->points;             // set by pf_set_scan
     h->h_pose.resize(PF_POSE_ROWS * P);
     // S3P:47-51 initial state, S3P:71-77 prior
     {
@@ -981,6 +1000,25 @@ int pf_read_map(pf_handle* h, int32_t i, uint8_t* dst) {
     return PF_OK;
 }
 
+// The beam lists pf_set_beams kept on the host (shared grid, default K1): sent when a call needs them.
+static int ensure_beam_lists(pf_handle* h, bool full, bool occ) {
+    bool sent = false;
+    if (full && !h->full_list_resident) {
+        if (h->M > 0) HIP_TRY(h, hipMemcpyAsync(h->beams, h->h_beams.data(), sizeof(PfBeam) * (size_t)h->M, hipMemcpyHostToDevice, h->stream));
+        h->full_list_resident = true; sent = true;
+    }
+    if (occ && !h->occ_lists_resident) {
+        if (h->M_occ > 0) {
+            HIP_TRY(h, hipMemcpyAsync(h->beams_occ, h->h_beams_occ.data(), sizeof(PfBeam) * (size_t)h->M_occ, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->beams_occ_f, h->h_beams_occ_f.data(), sizeof(PfBeamF) * (size_t)h->M_occ, hipMemcpyHostToDevice, h->stream));
+        }
+        h->occ_lists_resident = true; sent = true;
+    }
+    // (the sources are plain host vectors that the next pf_set_beams rewrites: the copies have to be through by then)
+    if (sent) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+}
+
 int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32_t* bz,
                  const int8_t* bv, int64_t n) {
     if (!h) return PF_ERR_ARG;
@@ -1115,40 +1153,46 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     }
     // everything goes through one pinned, double-buffered block: the call does not wait for the stream
     {
-        struct Seg { void* dev; const void* src; size_t bytes; };
+        // The shared grid's default K1 (column groups on the gather layout) reads the groups only: the full list
+        // (pf_voxel_indices) and the two occupied lists (the other K1 forms) then stay on the host until a call
+        // asks for them (ensure_beam_lists): 270 KB of the 320 KB a 4096-beam scan used to send every step.
+        static const bool eager = getenv("SLAM_PF_EAGER_LISTS") && atoi(getenv("SLAM_PF_EAGER_LISTS")) != 0;   // (for comparison)
+        const bool lazy = !eager && h->cfg.map_mode == PF_MAP_SHARED && h->shadow && !h->force_exact_measure && !box_eligible(h);
+        struct Seg { const void* src; size_t bytes; bool later; };
         const Seg segs[] = {
-            {nullptr, h->h_beams.data(), sizeof(PfBeam) * (size_t)n},
-            {nullptr, h->h_cols.data(), sizeof(PfColG) * h->h_cols.size()},
-            {nullptr, h->h_beams_occ.data(), sizeof(PfBeam) * no},
-            {nullptr, h->h_beams_occ_f.data(), sizeof(PfBeamF) * no},
-            {nullptr, h->h_colc.data(), h->box_groups > 0 ? sizeof(PfColG) * h->h_colc.size() : 0},
-            {nullptr, h->h_clusters.data(), h->box_groups > 0 ? sizeof(PfCluster) * h->h_clusters.size() : 0},
-            {nullptr, h->h_group_start.data(), h->box_groups > 0 ? sizeof(int) * h->h_group_start.size() : 0},
-            {nullptr, h->h_fcols.data(), h->n_fcols > 0 ? sizeof(PfFCol) * h->h_fcols.size() : 0},
-            {nullptr, h->h_fvals.data(), h->n_fcols > 0 ? h->h_fvals.size() : 0},
-            {nullptr, h->h_mcols.data(), h->n_mcols > 0 ? sizeof(PfFCol) * h->h_mcols.size() : 0},
-            {nullptr, h->h_mvals.data(), h->n_mcols > 0 ? h->h_mvals.size() : 0},
+            {h->h_cols.data(), sizeof(PfColG) * h->h_cols.size(), false},
+            {h->h_colc.data(), h->box_groups > 0 ? sizeof(PfColG) * h->h_colc.size() : 0, false},
+            {h->h_clusters.data(), h->box_groups > 0 ? sizeof(PfCluster) * h->h_clusters.size() : 0, false},
+            {h->h_group_start.data(), h->box_groups > 0 ? sizeof(int) * h->h_group_start.size() : 0, false},
+            {h->h_fcols.data(), h->n_fcols > 0 ? sizeof(PfFCol) * h->h_fcols.size() : 0, false},
+            {h->h_fvals.data(), h->n_fcols > 0 ? h->h_fvals.size() : 0, false},
+            {h->h_mcols.data(), h->n_mcols > 0 ? sizeof(PfFCol) * h->h_mcols.size() : 0, false},
+            {h->h_mvals.data(), h->n_mcols > 0 ? h->h_mvals.size() : 0, false},
+            {h->h_beams.data(), sizeof(PfBeam) * (size_t)n, lazy},                 // the lists that may wait come last,
+            {h->h_beams_occ.data(), sizeof(PfBeam) * no, lazy},                    // so what goes now is one run
+            {h->h_beams_occ_f.data(), sizeof(PfBeamF) * no, lazy},
         };
         size_t total = 64;
         for (const Seg& sg : segs) total += (sg.bytes + 63) & ~(size_t)63;
         if (total > h->beam_blk_bytes) return fail(h, PF_ERR_ARG, "pf_set_beams: beam lists beyond the handle's capacity");
         char* slot = nullptr;
         HIP_TRY(h, h->st_beams.acquire(total, &slot));
-        size_t off = 0;
+        size_t off = 0, now = 0;
         char* dev_at[11];
         int k = 0;
         for (const Seg& sg : segs) {
             dev_at[k++] = h->beam_blk + off;
             if (!sg.bytes) continue;
-            memcpy(slot + off, sg.src, sg.bytes);
+            if (!sg.later) { memcpy(slot + off, sg.src, sg.bytes); now = off + ((sg.bytes + 63) & ~(size_t)63); }
             off += (sg.bytes + 63) & ~(size_t)63;
         }
-        if (off) HIP_TRY(h, hipMemcpyAsync(h->beam_blk, slot, off, hipMemcpyHostToDevice, h->stream));
-        h->beams = (PfBeam*)dev_at[0]; h->beams_col = (PfColG*)dev_at[1]; h->beams_occ = (PfBeam*)dev_at[2];
-        h->beams_occ_f = (PfBeamF*)dev_at[3]; h->beams_colc = (PfColG*)dev_at[4]; h->clusters = (PfCluster*)dev_at[5];
-        h->group_start = (int*)dev_at[6];
-        h->fcols = (PfFCol*)dev_at[7]; h->fvals = (uint8_t*)dev_at[8];
-        h->mcols = (PfFCol*)dev_at[9]; h->mvals = (uint8_t*)dev_at[10];
+        if (now) HIP_TRY(h, hipMemcpyAsync(h->beam_blk, slot, now, hipMemcpyHostToDevice, h->stream));
+        h->beams_col = (PfColG*)dev_at[0]; h->beams_colc = (PfColG*)dev_at[1]; h->clusters = (PfCluster*)dev_at[2];
+        h->group_start = (int*)dev_at[3];
+        h->fcols = (PfFCol*)dev_at[4]; h->fvals = (uint8_t*)dev_at[5];
+        h->mcols = (PfFCol*)dev_at[6]; h->mvals = (uint8_t*)dev_at[7];
+        h->beams = (PfBeam*)dev_at[8]; h->beams_occ = (PfBeam*)dev_at[9]; h->beams_occ_f = (PfBeamF*)dev_at[10];
+        h->full_list_resident = h->occ_lists_resident = !lazy;
         HIP_TRY(h, h->st_beams.commit(h->stream));
     }
     h->M = (int)n;
@@ -1226,6 +1270,8 @@ int pf_measure(pf_handle* h, int add_points) {
         HIP_TRY(h, pfk_swz_build(h->stream, h->maps, h->shadow, h->swz));
         h->shadow_dirty = false;
     }
+    if (!box && !swz)                                  // the other forms read the occupied lists
+        if (int rc = ensure_beam_lists(h, false, true)) return rc;
     {
         Timed t(h, PF_K_MEASURE);
         if (box) {
@@ -1304,6 +1350,7 @@ int pf_voxel_indices(pf_handle* h, int32_t i, int32_t* flat_out) {
     NEED(h, flat_out || h->M == 0, "null output");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, materialize_pose(h));
+    if (int rc = ensure_beam_lists(h, true, false)) return rc;
     HIP_TRY(h, pfk_voxel_indices(h->stream, h->pose, h->P, i, h->beams, h->M, grid_params(h), h->vox));
     if (h->M)
         HIP_TRY(h, hipMemcpyAsync(flat_out, h->vox, sizeof(int32_t) * (size_t)h->M, hipMemcpyDeviceToHost, h->stream));
@@ -1504,30 +1551,38 @@ int pf_resample(pf_handle* h, const double* u, const void* poses_global_dev, int
     return pf_resample_result(h, best_out, nohit_out, ambiguous_out);
 }
 
+static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
 int pf_set_scan(pf_handle* h, const double* points, int64_t n_points, const int32_t* ray_idx,
                 int64_t n_rays) {
     if (!h) return PF_ERR_ARG;
     NEED(h, n_points >= 0 && n_points <= h->cfg.max_points, "n_points beyond max_points");
     NEED(h, n_rays >= 0 && n_rays <= h->cfg.max_points, "n_rays beyond max_points");
     NEED(h, (n_points == 0 || points) && (n_rays == 0 || ray_idx), "null array");
-    for (int64_t i = 0; i < 3 * n_points; ++i)
-        if (!(fabs(points[i]) < 1.0e6)) return fail(h, PF_ERR_ARG, "pf_set_scan: point %lld not finite/too far", (long long)(i / 3));
-    for (int64_t r = 0; r < n_rays; ++r)
-        if (ray_idx[r] < 0 || ray_idx[r] >= n_points)
-            return fail(h, PF_ERR_ARG, "pf_set_scan: ray_idx[%lld] outside [0, n_points)", (long long)r);
+    // checked in passes without an exit (they vectorise); the index is looked for only when something is wrong
+    {
+        bool ok = true;
+        for (int64_t i = 0; i < 3 * n_points; ++i) ok &= fabs(points[i]) < 1.0e6;
+        if (!ok)
+            for (int64_t i = 0; i < 3 * n_points; ++i)
+                if (!(fabs(points[i]) < 1.0e6)) return fail(h, PF_ERR_ARG, "pf_set_scan: point %lld not finite/too far", (long long)(i / 3));
+        ok = true;
+        for (int64_t r = 0; r < n_rays; ++r) ok &= (uint64_t)(int64_t)ray_idx[r] < (uint64_t)n_points;
+        if (!ok)
+            for (int64_t r = 0; r < n_rays; ++r)
+                if (ray_idx[r] < 0 || ray_idx[r] >= n_points)
+                    return fail(h, PF_ERR_ARG, "pf_set_scan: ray_idx[%lld] outside [0, n_points)", (long long)r);
+    }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, wait_map_writes(h));
     const size_t nb_p = sizeof(double) * 3 * (size_t)n_points, nb_r = sizeof(int32_t) * (size_t)n_rays;
+    const size_t off_r = up256(nb_p);                  // the ray indices' place in the block, on the host and the device
     char* slot = nullptr;
-    HIP_TRY(h, h->st_scan.acquire(nb_p + nb_r + 8, &slot));
-    if (n_points) {
-        memcpy(slot, points, nb_p);
-        HIP_TRY(h, hipMemcpyAsync(h->points, slot, nb_p, hipMemcpyHostToDevice, h->stream));
-    }
-    if (n_rays) {
-        memcpy(slot + nb_p, ray_idx, nb_r);
-        HIP_TRY(h, hipMemcpyAsync(h->ray_idx, slot + nb_p, nb_r, hipMemcpyHostToDevice, h->stream));
-    }
+    HIP_TRY(h, h->st_scan.acquire(off_r + nb_r + 8, &slot));
+    if (n_points) memcpy(slot, points, nb_p);
+    if (n_rays) memcpy(slot + off_r, ray_idx, nb_r);
+    h->ray_idx = (int32_t*)((char*)h->points + off_r);
+    if (n_points || n_rays)
+        HIP_TRY(h, hipMemcpyAsync(h->points, slot, n_rays ? off_r + nb_r : nb_p, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, h->st_scan.commit(h->stream));
     h->n_points = (int)n_points; h->n_rays = (int)n_rays;
     return PF_OK;
@@ -1583,7 +1638,6 @@ int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const dou
 }
 
 static int grow_scratch(pf_handle* h, size_t need);
-static size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
 int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const double pos[3],
                  const double zyx[3], int32_t n_yaw, int32_t yaw_k0, int32_t yaw_kstep,
                  int32_t n_t, double length, int32_t* sums_out, int64_t* best_out) {

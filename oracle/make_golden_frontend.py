@@ -394,6 +394,58 @@ def gen_local_map_ties(r):
     np.savez_compressed(os.path.join(OUT, "local_map_ties.npz"), **cases)
 
 
+def gen_vote_trig(r):
+    """scan_localization() at scan yaws where glibc's sincos() and sin()/cos() disagree in the last place (own
+    RNG). The epilogue S3P:379-380 turns the voted offset by -yaw: g++ -O2 takes the pair of S3P:379 from one
+    sincos(yaw) and calls sin(-yaw) again for S3P:380 (pf_host.cpp mirrors exactly that); with an offset of a
+    few voxels the last place of pos_xyz_diff_scan tells the forms apart."""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.cos.restype = libm.sin.restype = C.c_double
+    libm.cos.argtypes = libm.sin.argtypes = [C.c_double]
+    libm.sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rng = np.random.default_rng(7800)
+    want_kinds = ["sin", "cos", "both", "sin", "cos", "both"]
+    yaws = []
+    while len(yaws) < len(want_kinds):
+        a = float(rng.uniform(-3.0, 3.0))
+        sv, cv = C.c_double(), C.c_double()
+        libm.sincos(a, C.byref(sv), C.byref(cv))
+        ds, dc = sv.value != libm.sin(a) or -sv.value != libm.sin(-a), cv.value != libm.cos(a)
+        kind = "both" if ds and dc else "sin" if ds else "cos" if dc else None
+        if kind == want_kinds[len(yaws)]:
+            yaws.append(a)
+    cases = {}
+    for k, yaw in enumerate(yaws):
+        r.ref_slam_reset()
+        n = int(rng.integers(1500, 4000))
+        cloud = synthetic_cloud(rng, n)
+        pos = np.array([5.0, 5.0, 2.0]) + rng.uniform(-1.0, 1.0, 3) * [1, 1, 0.3]
+        off = np.array([2, -1, 1]) * 0.05 * rng.choice([-1, 1], 3) + rng.uniform(-0.01, 0.01, 3)    # a vote that moves the pose
+        w = cloud @ rot_zyx_np(yaw, 0.0, 0.0).T + pos + off
+        idx = np.rint(w * 20).astype(np.int64)
+        flat = idx[:, 0] * LY * LZ + idx[:, 1] * LZ + idx[:, 2]
+        flat = flat[(flat >= 0) & (flat < NL)]
+        g = loc_grid(r)
+        g[:] = 0; g[flat] = 1; g[rng.integers(0, NL, 2000)] = 1
+        grid_idx = np.flatnonzero(g).astype(np.int32)
+        r.ref_set_cloud(vp(cloud), n)
+        r.ref_set_scan_pose(*[float(v) for v in pos], float(yaw))
+        gyr = (yaw + rng.uniform(-0.05, 0.05), 0.0, 0.0)
+        before = dvec(r, "ref_get_scan_state", 18)
+        r.ref_set_gyr(*[float(v) for v in gyr])
+        seed, pick = screened_seed(r, 71000 + 31 * k, 500, n)
+        r.ref_set_seed(seed)
+        r.ref_scan_localization()
+        after = dvec(r, "ref_get_scan_state", 18)
+        name = f"c{k}_trig"
+        cases[name + "_grid_idx"] = grid_idx; cases[name + "_cloud_mm"] = mm16(cloud)
+        cases[name + "_gyr"] = np.array(gyr, np.float64); cases[name + "_seed"] = np.int64(seed)
+        cases[name + "_pick"] = pick; cases[name + "_before"] = before; cases[name + "_after"] = after
+        print(f"vote_trig {name}: yaw={yaw!r} loc={after[4:8]} diff={after[8:11]}")
+    np.savez_compressed(os.path.join(OUT, "vote_trig.npz"), **cases)
+
+
 def gen_ring(r, rng):
     """scan_localization_map_update() alone (S3P:419-529), poses set by the harness: keyframes whose
     points partly leave the grid (the non-compacted write of S3P:454-455), slot expiry, and
@@ -529,8 +581,11 @@ def main():
         sys.exit("oracle/_ref/libs3p_ref.so missing: run oracle/build_ref.sh (needs /root/reference)")
     os.makedirs(OUT, exist_ok=True)
     r = load_ref()
-    if len(sys.argv) > 1 and sys.argv[1] == "ties":         # the later addition, on its own: nothing else is rewritten
+    if len(sys.argv) > 1 and sys.argv[1] == "ties":         # the later additions, on their own: nothing else is rewritten
         gen_local_map_ties(r)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "vote_trig":
+        gen_vote_trig(r)
         return
     rng = np.random.default_rng(20261112)
     gen_helpers_p(r, rng)
@@ -540,6 +595,7 @@ def main():
     gen_ring(r, rng)
     gen_frames(r, rng)
     gen_local_map_ties(r)
+    gen_vote_trig(r)
     print("front-end fixtures written to", OUT)
 
 

@@ -43,12 +43,12 @@ def full_image(pooled):
 
 
 # ---- scan_localization(): vote.npz ------------------------------------------------------------
-def check_vote_cases(golden_dir, make_loc):
-    """make_loc() -> a fresh localisation handle (grid all zero). Every case of vote.npz: members
+def check_vote_cases(golden_dir, make_loc, fixture="vote.npz", at_least=10):
+    """make_loc() -> a fresh localisation handle (grid all zero). Every case of the fixture: members
     before the call -> the members the reference's scan_localization() left (S3P:300-410)."""
-    g = load(golden_dir, "vote.npz")
+    g = load(golden_dir, fixture)
     names = case_names(g, "_seed")
-    assert len(names) >= 10
+    assert len(names) >= at_least
     for name in names:
         loc = make_loc()
         grid = np.zeros(NL, np.uint8); grid[g[name + "_grid_idx"]] = 1

@@ -41,6 +41,14 @@ def test_scan_vote_matches_reference(golden_dir):
     G.check_vote_cases(golden_dir, loc_handle)
 
 
+def test_scan_vote_epilogue_trig_matches_reference(golden_dir):
+    """scan_localization() of the reference at scan yaws where glibc's sincos() and sin()/cos() disagree in the
+    last place (tests/golden/vote_trig.npz, `oracle/make_golden_frontend.py vote_trig`): pins the epilogue's
+    sines and cosines (S3P:379-380: one sincos(yaw) for the first line, a separate sin(-yaw) for the second, as
+    g++ -O2 compiles it and slam_amd/csrc/pf_host.cpp writes it) to the reference build itself."""
+    G.check_vote_cases(golden_dir, loc_handle, "vote_trig.npz", 6)
+
+
 def test_local_map_update_matches_reference(golden_dir):
     G.check_local_map_cases(golden_dir, mapper_handle)
 

@@ -264,6 +264,59 @@ def gen_steps(r, rng):
               f"max w_pre={out['w_pre'].max():.4g}")
 
 
+def gen_step_trig(r):
+    """One particle_map() call (S3P:827-962) whose particles all sit at yaws where glibc's sincos() and
+    sin()/cos() disagree in the last place (own RNG; written on its own by `make_golden.py step_trig`): g++ -O2
+    takes the rotation of S3P:860 and the predict of S3P:911-912 from sincos(), and the local-frame motion is
+    large enough for that last place to show in the predicted poses."""
+    libm = C.CDLL("libm.so.6")
+    libm.cos.restype = libm.sin.restype = C.c_double
+    libm.cos.argtypes = libm.sin.argtypes = [C.c_double]
+    libm.sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rng = np.random.default_rng(7900)
+    world = world_map(rng)
+    true_pose = np.array([7.5, 7.5, 1.5, 0.3])
+    P, add, seed = 50, 1, 505
+    yaws = []
+    while len(yaws) < P:
+        a = float(true_pose[3] + rng.normal(0, 0.05))
+        sv, cv = C.c_double(), C.c_double()
+        libm.sincos(a, C.byref(sv), C.byref(cv))
+        if sv.value != libm.sin(a) or cv.value != libm.cos(a):
+            yaws.append(a)
+    r.ref_alloc_particles(P)
+    local = local_scan(world, true_pose, rng, n_occ=900, n_free=250, n_weak=80)
+    st = np.empty((P, 5))
+    st[:, 0] = true_pose[0] + rng.normal(0, 0.06, P)
+    st[:, 1] = true_pose[1] + rng.normal(0, 0.06, P)
+    st[:, 2] = true_pose[2] + rng.normal(0, 0.03, P)
+    st[:, 3] = yaws
+    st[:, 4] = 1.0 / P
+    local_pose = np.array([9.63, 0.71, 1.52, 0.04])          # a long local-frame motion: the last place of c, s reaches the poses
+    global_pose = np.array([7.9, 7.4, 1.5, 0.33])
+    policy = dict(add=add, last=[7.5, 7.5, 1.5, 0.0], best=int(rng.integers(0, P)))
+    out = run_step(r, P, world, st, local, local_pose, global_pose, policy, seed)
+    noise, u = streams(r, P, seed)
+    crcs = np.array([zlib.crc32(pmap(r, i).tobytes()) for i in range(P)], np.uint32)
+    d = {}
+    for i in (0, 1, P - 1):
+        idx, val = sparse(pmap(r, i).copy(), world)
+        d[f"map{i}_idx"] = idx; d[f"map{i}_val"] = val
+    lidx = np.flatnonzero(local.reshape(-1)).astype(np.int32)
+    np.savez_compressed(
+        os.path.join(OUT, "step_P50_trig.npz"),
+        P=np.int32(P), add=np.int32(add), seed=np.int32(seed),
+        world=world, local_idx=lidx, local_val=local.reshape(-1)[lidx],
+        state_in=st, local_pose=local_pose, global_pose=global_pose,
+        last_in=np.array(policy["last"]), best_in=np.int32(policy["best"]),
+        noise=noise, u=u, w_pre=out["w_pre"], state_out=out["state"],
+        add_after=np.int32(out["add_after"]), best=np.int32(out["best"]),
+        last_after=out["last_after"], feedback=out["feedback"],
+        local_pose_after=out["local_pose_after"],
+        local_after_nonzero=np.int32(out["local_after_nonzero"]), map_crc=crcs, **d)
+    print(f"step_trig P={P}: beams={len(lidx)} best={out['best']}")
+
+
 def gen_run(r, rng, P=100, steps=200):
     """BASELINE.json configs[0]: P=100, ~1k-beam scans, 200 consecutive steps of the
     reference's particle_map(); maps and particles carry over from step to step."""
@@ -336,12 +389,16 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     r = load_ref()
     assert r.ref_p_map_elements() == PX * PY * PZ and r.ref_map_elements() == LX * LY * LZ
+    if len(sys.argv) > 1 and sys.argv[1] == "step_trig":    # the later addition, on its own: nothing else is rewritten
+        gen_step_trig(r)
+        return
     rng = np.random.default_rng(20261111)
     gen_helpers(r, rng)
     gen_resample(r, rng)
     gen_steps(r, rng)
     if "--no-run" not in sys.argv:
         gen_run(r, rng)
+    gen_step_trig(r)
     print("fixtures written to", OUT)
 
 

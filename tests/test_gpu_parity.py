@@ -33,7 +33,7 @@ def test_library_is_the_hip_build():
     assert all(hasattr(L, s) for s in capi.SYMBOLS)
 
 
-@pytest.mark.parametrize("name", ["step_P50_add1", "step_P50_add0", "step_P100_add1",
+@pytest.mark.parametrize("name", ["step_P50_trig", "step_P50_add1", "step_P50_add0", "step_P100_add1",
                                   "step_P100_add0"])
 def test_reference_single_step(golden_dir, name):
     """One particle_map() call of the reference, reference sizes, per-particle maps."""

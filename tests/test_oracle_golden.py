@@ -81,7 +81,7 @@ def test_resample_uniform_stream_matches_libstdcxx(golden_dir):
         assert np.array_equal(capi.draw_uniform(seed, len(g[n + "_u"])), g[n + "_u"]), n
 
 
-@pytest.mark.parametrize("name", ["step_P50_add1", "step_P50_add0", "step_P100_add1",
+@pytest.mark.parametrize("name", ["step_P50_trig", "step_P50_add1", "step_P50_add0", "step_P100_add1",
                                   "step_P100_add0"])
 def test_single_step_matches_reference(golden_dir, name):
     g = load(golden_dir, name + ".npz")

@@ -446,6 +446,62 @@ def gen_vote_trig(r):
     np.savez_compressed(os.path.join(OUT, "vote_trig.npz"), **cases)
 
 
+def gen_local_map_trig(r):
+    """build_local_map() with the GLOBAL yaw at angles where glibc's sincos() and sin()/cos() disagree (own
+    RNG): update_realtime_pos() (S3P:712-728) turns the scan-pose increment by it, from one sincos() in the
+    g++ -O2 build; increments of a few metres let the last place reach the dead-reckoned pose."""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.cos.restype = libm.sin.restype = C.c_double
+    libm.cos.argtypes = libm.sin.argtypes = [C.c_double]
+    libm.sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rng = np.random.default_rng(8100)
+    cases = {}
+    k = 0
+    while k < 8:
+        a = float(rng.uniform(-3.0, 3.0))
+        sv, cv = C.c_double(), C.c_double()
+        libm.sincos(a, C.byref(sv), C.byref(cv))
+        if sv.value == libm.sin(a) and cv.value == libm.cos(a):
+            continue
+        r.ref_slam_reset()
+        n = 700
+        cloud = synthetic_cloud(rng, n)
+        pre = np.zeros(NL, np.int8)
+        local_pose = np.array([5.0, 5.0, 1.5, 0.0]) + rng.uniform(-0.3, 0.3, 4)
+        diffs = np.array([*rng.uniform(-2.5, 2.5, 2), rng.uniform(-0.05, 0.05), 0.0])
+        gpose = np.array([0.0, 0.0, 1.5, a]) + np.array([*rng.uniform(-0.5, 0.5, 2), 0.0, 0.0])
+        fb = np.zeros(4)
+        local_grid(r)[:] = pre
+        r.ref_set_cloud(vp(cloud), n)
+        r.ref_set_local_pose(*[float(v) for v in local_pose])
+        r.ref_set_global_pose(*[float(v) for v in gpose])
+        r.ref_set_feedback(*[float(v) for v in fb])
+        r.ref_set_diffs(*[float(v) for v in diffs])
+        r.ref_set_rot_yx(0.0, 0.0)
+        seed, rays = screened_seed(r, 53000 + 13 * k, 2400, n)
+        r.ref_set_seed(seed)
+        r.ref_build_local_map()
+        post = local_grid(r).copy()
+        touched = np.flatnonzero(post != pre).astype(np.int32)
+        lp = dvec(r, "ref_get_local_pose", 4); gp = dvec(r, "ref_get_global_pose", 4)
+        fb_after = dvec(r, "ref_get_feedback", 4)
+        name = f"g{k}_trig"
+        cases[name + "_cloud_mm"] = mm16(cloud)
+        cases[name + "_pre_k"] = np.int64(-1)
+        cases[name + "_local_pose"] = local_pose; cases[name + "_diffs"] = diffs
+        cases[name + "_rot_yx"] = np.array([0.0, 0.0]); cases[name + "_gpose"] = gpose; cases[name + "_fb"] = fb
+        cases[name + "_seed"] = np.int64(seed); cases[name + "_rays"] = rays
+        cases[name + "_touched"] = touched; cases[name + "_touched_val"] = post[touched]
+        cases[name + "_map_crc"] = crc(post)
+        cases[name + "_local_pose_after"] = lp; cases[name + "_gpose_after"] = gp; cases[name + "_fb_after"] = fb_after
+        # would separate calls have given another pose? (printed for the record)
+        alt = gpose[0] + (libm.cos(a) * diffs[0] - libm.sin(a) * diffs[1] + 0.0)
+        print(f"local_map_trig {name}: yaw={a!r} gpose_after={gp[:2]} separate-calls x differs: {alt != gp[0]}")
+        k += 1
+    np.savez_compressed(os.path.join(OUT, "local_map_trig.npz"), **cases)
+
+
 def gen_ring(r, rng):
     """scan_localization_map_update() alone (S3P:419-529), poses set by the harness: keyframes whose
     points partly leave the grid (the non-compacted write of S3P:454-455), slot expiry, and
@@ -587,6 +643,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "vote_trig":
         gen_vote_trig(r)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "local_map_trig":
+        gen_local_map_trig(r)
+        return
     rng = np.random.default_rng(20261112)
     gen_helpers_p(r, rng)
     gen_depth(r, rng)
@@ -596,6 +655,7 @@ def main():
     gen_frames(r, rng)
     gen_local_map_ties(r)
     gen_vote_trig(r)
+    gen_local_map_trig(r)
     print("front-end fixtures written to", OUT)
 
 

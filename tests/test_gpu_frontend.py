@@ -53,6 +53,14 @@ def test_local_map_update_matches_reference(golden_dir):
     G.check_local_map_cases(golden_dir, mapper_handle)
 
 
+def test_dead_reckoned_pose_trig_matches_reference(golden_dir):
+    """build_local_map() of the reference with the GLOBAL yaw at angles where glibc's sincos() and sin()/cos()
+    disagree (tests/golden/local_map_trig.npz, `oracle/make_golden_frontend.py local_map_trig`): pins
+    pfh_update_realtime_pos (S3P:712-728, one sincos() for both lines in the g++ -O2 build) to the reference build;
+    scan-pose increments of metres let the last place reach the dead-reckoned pose."""
+    G.check_local_map_cases(golden_dir, mapper_handle, "local_map_trig.npz", 8)
+
+
 def test_local_map_update_on_rounding_ties_matches_reference(golden_dir):
     """build_local_map() of the reference where its roundings sit on ties (tests/golden/local_map_ties.npz,
     made by `oracle/make_golden_frontend.py ties` from the reference's own class Slam): scan points at odd

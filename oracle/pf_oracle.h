@@ -103,7 +103,7 @@ void pfo_update_map(const pfo_update_cfg* c, void* grid,
                     int64_t M, const double* points, int64_t R, const int32_t* ray_idx);
 
 /* ---- keyframe ring of the localisation grid: S3P:286-289, 305-312, 419-529 --
- * PARITY UNPINNED (members of class Slam, like pfo_scan_vote). The ring keeps, for n_slots past
+ * Pinned since round 2 to the reference's own class Slam (tests/golden/ring.npz, frames.npz). The ring keeps, for n_slots past
  * scans, the flat indices their points fell on; live slots are painted into the binary grid
  * before every vote, a slot is replaced when the pose has moved, and everything is shifted by a
  * flat-index offset when the sensor leaves the middle of the grid.
@@ -135,8 +135,8 @@ void pfo_ring_paint(const pfo_ring* r, uint8_t* grid);
 int pfo_ring_update(pfo_ring* r, uint8_t* grid, int64_t n, const double* cloud, double pos_scan[3],
                     const double zyx[3]);
 
-/* ---- depth front-end: S3P:116-124, 155-162, 562-612. PARITY UNPINNED (class
- * members). image: height rows of width little-endian uint16 depths in millimetres (the bytes of
+/* ---- depth front-end: S3P:116-124, 155-162, 562-612. Pinned since round 2 to the
+ * reference's own callback() body (tests/golden/depth.npz). image: height rows of width little-endian uint16 depths in millimetres (the bytes of
  * sensor_msgs/Image, S3P:587); pooled pool x pool (S3P:580-594: integer mean that ignores zeros),
  * pinhole tables from focal = the pooled focal length (S3P:124: 385/4), integer millimetre
  * products truncated toward zero (S3P:567-568 assign a double to an int), then metres; pixels

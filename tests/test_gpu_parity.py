@@ -462,8 +462,9 @@ def _update_case(signed, dims, seed):
 
 
 def test_update_map_local_int8_matches_oracle():
-    """S3P:628-704 on the reference's int8 local map. PARITY UNPINNED by the reference (see
-    oracle/pf_oracle.h): checked against the restatement."""
+    """S3P:628-704 on the reference's int8 local map, against the restatement on a scene of this test's own
+    (the restatement is pinned to the reference's build_local_map() by tests/golden/local_map*.npz, and the
+    library to those fixtures directly by tests/test_gpu_frontend.py)."""
     dims = (200, 200, 80)
     grid, pos, zyx, pts, ray_idx, prm = _update_case(True, dims, 11)
     cfg = O.UpdateCfg(dims[0], dims[1], dims[2], 0.05, 1, prm[0], prm[1], prm[2], prm[3], 3.0)
@@ -884,8 +885,9 @@ def test_sharded_handles_at_nonzero_offsets_equal_one_gpu(world):
 @pytest.mark.parametrize("seed,n_points", [(21, 500), (22, 37), (23, 0)])
 def test_scan_vote_matches_oracle(seed, n_points):
     """S3P:328-376 (625 pose hypotheses x 500 points on the binary localisation grid).
-    PARITY UNPINNED by the reference (scan_localization is a class member, not buildable
-    here; see oracle/pf_oracle.h): checked against the restatement, integer-exact."""
+    Against the restatement on scenes of this test's own; the restatement is pinned to the reference's
+    scan_localization() by tests/golden/vote*.npz (tests/test_frontend_golden.py) and the library to those
+    fixtures directly (tests/test_gpu_frontend.py). Integer-exact."""
     rng = np.random.default_rng(seed)
     dims = (200, 200, 80)
     world = synth.make_room(dims, seed=seed)
@@ -949,9 +951,9 @@ def _ring_frames(dims, n_frames, cap, seed):
 
 def test_keyframe_ring_matches_oracle():
     """S3P:305-312, 419-529: slot replacement with the non-compacted write,
-    painting, erasing, and the flat-offset recentring. PARITY UNPINNED by the reference (members
-    of class Slam): checked against the restatement, every index of every slot after every
-    frame, then a vote (K6) on the painted grid."""
+    painting, erasing, and the flat-offset recentring. Against the restatement (pinned to the
+    reference's scan_localization_map_update() by tests/golden/ring.npz and frames.npz): every index of every slot
+    after every frame, then a vote (K6) on the painted grid."""
     dims = (120, 100, 48)
     cap = 3000
     frames = _ring_frames(dims, 45, cap, 7)

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libslam_pf.so")
+LIB_PATH = os.environ.get("SLAM_PF_LIB") or os.path.join(_HERE, "csrc", "libslam_pf.so")   # (SLAM_PF_LIB: development builds)
 
 PF_OK = 0
 PF_MAP_SHARED, PF_MAP_PER_PARTICLE = 0, 1

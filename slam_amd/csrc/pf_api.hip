@@ -108,7 +108,10 @@ struct pf_handle {
     PfBeam* beams_occ = nullptr;       // [max_beams] occupied beams only (fast measure path)
     PfBeamF* beams_occ_f = nullptr;    // [max_beams] the same in fp32
     PfColG* beams_col = nullptr;       // [max_beams] the same grouped by local column (k_measure_col)
+    PfTileG* beams_tile = nullptr;     // [max_beams] the same groups as k_measure_tile reads them
     std::vector<PfColG> h_cols, h_sort_tmp;
+    std::vector<PfTileG> h_tcols;      // h_cols as k_measure_tile reads them
+    int lz_min = 0, lz_max = 0;        // bounds of lz over the occupied beams
     std::vector<unsigned long long> h_sort_keys;
     // k_measure_box: the same groups ordered by cluster, the clusters ordered by blockIdx.y group
     PfColG* beams_colc = nullptr;      // [max_beams]
@@ -133,7 +136,12 @@ struct pf_handle {
     int n_mcols = 0;
     int n_fcols = 0;                   // 0: the beam list does not qualify, k_measure_fuse_wave takes the step
     int partial_rows = 1;              // rows of `partial` (chunks of the col kernels / groups of the box kernel)
-    int k1_mode = 0;                   // SLAM_PF_K1: 0 auto, 1 col (gather layout), 2 box (LDS) whenever possible
+    int k1_mode = 0;                   // SLAM_PF_K1: 0 auto (= tile), 1 col (brick layout, byte gathers), 2 box (LDS), 3 tile
+    int lanes = 0;                     // lanes of K1's order: P, or pfk_padded_lanes(P) with z classes (k_measure_tile)
+    bool zsplit = false;               // the lane order keeps one round(z/res) per wave (PfOrderParams::zsplit)
+    int n_bmin = 0;                    // entries of bmin: ceil(lanes/64)
+    int32_t* order_ext = nullptr;      // [2][PF_EXT_WORDS] extent of the cloud by the last two lane orderings (PfOrderParams::ext)
+    int ext_cur = -1;                  // the record the last ordering filled (-1: none yet); the other one is empty
     double yaw_hint = 0.0;             // mean yaw of the last host-side predict: aligns the clusters with the grid
     int n_cols = 0;
     int n_runs = 0;                    // beams_col[0 .. n_runs): run groups (8-cell z windows)
@@ -603,7 +611,7 @@ void pf_destroy(pf_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->bmin_ext, h->bmin_all, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beam_blk,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
-                    h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_hist[0], h->order_hist[1], h->points, h->wpts};
+                    h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_ext, h->order_hist[0], h->order_hist[1], h->points, h->wpts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : h->ev) for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -665,11 +673,30 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     h->local_elements = (long long)c.local_x * c.local_y * c.local_z;
     h->slab = c.map_mode == PF_MAP_PER_PARTICLE ? round_up((unsigned long long)h->elements, 256) : 0;
     h->exact = c.order_mode == PF_ORDER_EXACT || (c.order_mode == PF_ORDER_AUTO && h->Pg <= 2048);
+    if (const char* e = getenv("SLAM_PF_K1")) h->k1_mode = !strcmp(e, "col") ? 1 : !strcmp(e, "box") ? 2 : !strcmp(e, "tile") ? 3 : 0;
+    if (const char* e = getenv("SLAM_PF_EXACT_MEASURE")) h->force_exact_measure = atoi(e);
+    // K1's copy of the shared grid: tiles (k_measure_tile, the default) when gz*a fits 32-bit byte offsets,
+    // else / on request bricks (k_measure_col)
+    int layout = -1;
+    unsigned long long lay_a = 0, lay_b = 0, lay_bytes = 0;
+    if (c.map_mode == PF_MAP_SHARED && h->elements < (1ll << 31) && !getenv("SLAM_PF_NO_GATHER_LAYOUT")) {
+        const unsigned long long gx = c.grid_x, gy = c.grid_y, gz = c.grid_z;
+        const unsigned long long ntx = (gx + 7) / 8 + 2, nty = (gy + 7) / 8 + 2;
+        const unsigned long long tb = ntx * 64, ta = nty * tb;
+        const unsigned long long nx4 = (gx + 3) / 4, ny4 = (gy + 3) / 4, nz4 = (gz + 3) / 4;
+        const unsigned long long sa = ny4 * nz4 * 64, sb = nz4 * 64, sbytes = nx4 * sa;
+        const bool bricks_fit = sa < (1ull << 24) && nx4 < (1ull << 24) && ny4 < (1ull << 24) && sbytes < (1ull << 32);
+        if ((h->k1_mode == 0 || h->k1_mode == 3) && gz * ta < (1ull << 32)) { layout = PF_LAYOUT_TILES; lay_a = ta; lay_b = tb; lay_bytes = gz * ta; }
+        else if (bricks_fit) { layout = PF_LAYOUT_BRICKS; lay_a = sa; lay_b = sb; lay_bytes = sbytes; }
+    }
+    h->zsplit = layout == PF_LAYOUT_TILES && !h->force_exact_measure;
+    h->lanes = h->zsplit ? pfk_padded_lanes(h->P) : h->P;
+    h->n_bmin = (h->lanes + 63) / 64;
     // beam chunks: enough waves to fill 256 CUs x 4 SIMDs several times over
     {
         // at most 2048 blocks of 256 threads = one full residency of 256 CUs x 8 blocks: every
         // block does the same amount of work, so a second, partly filled round would be a tail
-        const int blocks_x = (h->P + 255) / 256;
+        const int blocks_x = (h->lanes + 255) / 256;
         int ch = 2048 / blocks_x;
         if (ch < 1) ch = 1;
         if (ch > 1024) ch = 1024;
@@ -698,26 +725,18 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     const unsigned long long map_bytes =
         c.map_mode == PF_MAP_PER_PARTICLE ? h->slab * P : round_up((unsigned long long)h->elements, 256);
     CREATE_TRY(dalloc(&h->maps, (size_t)map_bytes));
-    CREATE_TRY(dalloc(&h->sorted, 5 * P));
-    {
-        // gather-layout copy for K1 when the 24-bit multiplies and 32-bit byte offsets of
-        // swz_addr hold (any grid up to 1024^3 does); otherwise K1 reads the reference order
-        const unsigned long long gx = c.grid_x, gy = c.grid_y, gz = c.grid_z;
-        const unsigned long long nx4 = (gx + 3) / 4, ny4 = (gy + 3) / 4, nz4 = (gz + 3) / 4;
-        const unsigned long long sa = ny4 * nz4 * 64, sb = nz4 * 64, sbytes = nx4 * sa;
-        const bool fits = sa < (1ull << 24) && nx4 < (1ull << 24) && ny4 < (1ull << 24);
-        if (c.map_mode == PF_MAP_SHARED && fits && sbytes < (1ull << 32) &&
-            h->elements < (1ll << 31) && !getenv("SLAM_PF_NO_GATHER_LAYOUT")) {
-            CREATE_TRY(dalloc(&h->shadow, (size_t)round_up(sbytes, 256)));
-            CREATE_TRY(hipMemsetAsync(h->shadow, 0, (size_t)round_up(sbytes, 256), h->stream));
-            h->swz = PfSwz{(uint32_t)gx, (uint32_t)gy, (uint32_t)gz, (uint32_t)sa, (uint32_t)sb};
-        }
+    CREATE_TRY(dalloc(&h->sorted, 5 * (size_t)h->lanes));
+    if (layout >= 0) {
+        // gather-layout copy for K1 (any grid up to 1024^3 has one); otherwise K1 reads the reference order
+        CREATE_TRY(dalloc(&h->shadow, (size_t)round_up(lay_bytes, 256)));
+        CREATE_TRY(hipMemsetAsync(h->shadow, 0, (size_t)round_up(lay_bytes, 256), h->stream));
+        h->swz = PfSwz{(uint32_t)c.grid_x, (uint32_t)c.grid_y, (uint32_t)c.grid_z, (uint32_t)lay_a, (uint32_t)lay_b, (uint32_t)layout};
     }
     if (h->local_elements)
         CREATE_TRY(dalloc(&h->local, (size_t)round_up((unsigned long long)h->local_elements, 256)));
     {
         const size_t mb = (size_t)c.max_beams;
-        h->beam_blk_bytes = 64 * 8 + sizeof(PfBeam) * mb + sizeof(PfColG) * (mb + 1) + sizeof(PfBeam) * (mb + PF_BEAM_GROUP) +
+        h->beam_blk_bytes = 64 * 9 + sizeof(PfBeam) * mb + sizeof(PfTileG) * (mb + 1) + sizeof(PfColG) * (mb + 1) + sizeof(PfBeam) * (mb + PF_BEAM_GROUP) +
                             sizeof(PfBeamF) * (mb + PF_BEAM_GROUP) + sizeof(PfColG) * (mb + 1) + sizeof(PfCluster) * (mb + 1) +
                             sizeof(int) * 257;
         if (c.map_mode == PF_MAP_PER_PARTICLE)      // worst case, every beam a column of its own: 32 B + two units
@@ -725,15 +744,13 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
         CREATE_TRY(hipMalloc((void**)&h->beam_blk, h->beam_blk_bytes));
         h->beams = (PfBeam*)h->beam_blk;       // (real offsets are set by every pf_set_beams)
     }
-    if (const char* e = getenv("SLAM_PF_K1")) h->k1_mode = !strcmp(e, "col") ? 1 : !strcmp(e, "box") ? 2 : 0;
     if (const char* e = getenv("SLAM_PF_TWO_GATHERS")) h->group_gathers = atoi(e) == 0;
     if (const char* e = getenv("SLAM_PF_CHUNKS")) h->tune_chunks = atoi(e);
     if (h->tune_chunks > h->max_chunks) h->max_chunks = h->tune_chunks < 1024 ? h->tune_chunks : 1024;
-    if (const char* e = getenv("SLAM_PF_EXACT_MEASURE")) h->force_exact_measure = atoi(e);
     h->partial_rows = std::max(h->max_chunks, 256 / (((int)P + 4095) / 4096));
-    CREATE_TRY(dalloc(&h->partial, (size_t)h->partial_rows * P));
+    CREATE_TRY(dalloc(&h->partial, (size_t)h->partial_rows * (size_t)h->lanes));
     CREATE_TRY(dalloc(&h->scores, P));
-    CREATE_TRY(dalloc(&h->bmin, (P + 63) / 64));
+    CREATE_TRY(dalloc(&h->bmin, (size_t)h->n_bmin));
     CREATE_TRY(dalloc(&h->bmin_ext, (size_t)pfk_block_minima_count((int)Pg)));
     CREATE_TRY(dalloc(&h->draw, Pg));
     CREATE_TRY(dalloc(&h->first, Pg));
@@ -768,8 +785,14 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
         h->rs.ndup = (int32_t*)q;
     }
     CREATE_TRY(dalloc(&h->vox, (size_t)c.max_beams));
-    CREATE_TRY(dalloc(&h->order, P));
+    CREATE_TRY(dalloc(&h->order, (size_t)h->lanes));
     CREATE_TRY(dalloc(&h->order_keys, P));
+    {
+        int32_t empty[2 * PF_EXT_WORDS];
+        for (int k = 0; k < 2 * PF_EXT_WORDS; ++k) empty[k] = ((k / PF_EXT_STRIDE) & 1) ? INT32_MIN : INT32_MAX;
+        CREATE_TRY(dalloc(&h->order_ext, (size_t)2 * PF_EXT_WORDS));
+        CREATE_TRY(hipMemcpy(h->order_ext, empty, sizeof empty, hipMemcpyHostToDevice));
+    }
     CREATE_TRY(dalloc(&h->order_hist[0], (size_t)PF_ORDER_BUCKETS));
     CREATE_TRY(dalloc(&h->order_hist[1], (size_t)PF_ORDER_BUCKETS));
     CREATE_TRY(hipMemsetAsync(h->order_hist[0], 0, sizeof(int32_t) * PF_ORDER_BUCKETS, h->stream));
@@ -1007,7 +1030,8 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     // chunk the same share of it
     h->h_cols.clear();
     std::vector<PfColG> runs;
-    static const bool use_runs = !(getenv("SLAM_PF_RUNS") && atoi(getenv("SLAM_PF_RUNS")) == 0);
+    static const bool runs_wanted = !(getenv("SLAM_PF_RUNS") && atoi(getenv("SLAM_PF_RUNS")) == 0);
+    const bool use_runs = runs_wanted && !(h->shadow && h->swz.kind == PF_LAYOUT_TILES);   // (the tile kernel takes plain groups)
     {
         std::vector<int32_t> zs, rest;
         for (int j = 0; j < n_real_occ;) {
@@ -1085,6 +1109,21 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
             h->col_ends[4 - n] = e;
         }
     }
+    const bool tiles = h->shadow && h->swz.kind == PF_LAYOUT_TILES;
+    if (tiles) {
+        int zmin = INT32_MAX, zmax = INT32_MIN;
+        for (const PfColG& g : h->h_cols) { zmin = std::min(zmin, g.lz[0]); zmax = std::max(zmax, g.lz[g.n - 1]); }
+        if (h->h_cols.empty()) zmin = zmax = 0;
+        h->lz_min = zmin; h->lz_max = zmax;
+        h->h_tcols.resize(h->h_cols.size());
+        for (size_t i = 0; i < h->h_cols.size(); ++i) {
+            const PfColG& g = h->h_cols[i];
+            PfTileG t{};
+            t.lx = g.lx; t.ly = g.ly; t.n = g.n;
+            for (int k = 0; k < 4; ++k) t.lza[k] = (uint32_t)(g.lz[k] - zmin) * h->swz.a;   // (mod 2^32: used only when the layer is inside the grid)
+            h->h_tcols[i] = t;
+        }
+    }
     // everything goes through one pinned, double-buffered block: the call does not wait for the stream
     {
         // The shared grid's default K1 (column groups on the gather layout) reads the groups only: the full list
@@ -1095,6 +1134,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         struct Seg { const void* src; size_t bytes; bool later; };
         const Seg segs[] = {
             {h->h_cols.data(), sizeof(PfColG) * h->h_cols.size(), false},
+            {h->h_tcols.data(), tiles ? sizeof(PfTileG) * h->h_tcols.size() : 0, false},
             {h->h_colc.data(), h->box_groups > 0 ? sizeof(PfColG) * h->h_colc.size() : 0, false},
             {h->h_clusters.data(), h->box_groups > 0 ? sizeof(PfCluster) * h->h_clusters.size() : 0, false},
             {h->h_group_start.data(), h->box_groups > 0 ? sizeof(int) * h->h_group_start.size() : 0, false},
@@ -1112,7 +1152,7 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         char* slot = nullptr;
         HIP_TRY(h, h->st_beams.acquire(total, &slot));
         size_t off = 0, now = 0;
-        char* dev_at[11];
+        char* dev_at[12];
         int k = 0;
         for (const Seg& sg : segs) {
             dev_at[k++] = h->beam_blk + off;
@@ -1121,11 +1161,12 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
             off += (sg.bytes + 63) & ~(size_t)63;
         }
         if (now) HIP_TRY(h, hipMemcpyAsync(h->beam_blk, slot, now, hipMemcpyHostToDevice, h->stream));
-        h->beams_col = (PfColG*)dev_at[0]; h->beams_colc = (PfColG*)dev_at[1]; h->clusters = (PfCluster*)dev_at[2];
-        h->group_start = (int*)dev_at[3];
-        h->fcols = (PfFCol*)dev_at[4]; h->fvals = (uint8_t*)dev_at[5];
-        h->mcols = (PfFCol*)dev_at[6]; h->mvals = (uint8_t*)dev_at[7];
-        h->beams = (PfBeam*)dev_at[8]; h->beams_occ = (PfBeam*)dev_at[9]; h->beams_occ_f = (PfBeamF*)dev_at[10];
+        h->beams_col = (PfColG*)dev_at[0]; h->beams_tile = (PfTileG*)dev_at[1];
+        h->beams_colc = (PfColG*)dev_at[2]; h->clusters = (PfCluster*)dev_at[3];
+        h->group_start = (int*)dev_at[4];
+        h->fcols = (PfFCol*)dev_at[5]; h->fvals = (uint8_t*)dev_at[6];
+        h->mcols = (PfFCol*)dev_at[7]; h->mvals = (uint8_t*)dev_at[8];
+        h->beams = (PfBeam*)dev_at[9]; h->beams_occ = (PfBeam*)dev_at[10]; h->beams_occ_f = (PfBeamF*)dev_at[11];
         h->full_list_resident = h->occ_lists_resident = !lazy;
         HIP_TRY(h, h->st_beams.commit(h->stream));
     }
@@ -1144,18 +1185,23 @@ bool box_eligible(const pf_handle* h) {
     // opt-in (SLAM_PF_K1=box): measured slower than the gather-layout kernel at every BASELINE size so
     // far (the per-cluster barrier makes every wave wait for the one with the most
     // fp64-corrected columns, and the sparse bench scan stages 15 KB per nine beams)
-    return h->cfg.map_mode == PF_MAP_SHARED && h->cfg.grid_z % 4 == 0 && !h->force_exact_measure && h->k1_mode == 2;
+    return h->cfg.map_mode == PF_MAP_SHARED && h->cfg.grid_z % 4 == 0 && !h->force_exact_measure && h->k1_mode == 2 && !h->zsplit;
 }
 }  // namespace
 static PfOrderParams order_params(const pf_handle* h) {
-    PfOrderParams op{200.0, 3.0, 3.0, 1, h->P <= 65536 ? 4 : 5};
+    PfOrderParams op{200.0, 3.0, 3.0, 1, h->P <= 65536 ? 4 : 5, 0, nullptr};
+    // k_measure_tile: the top three key bits are the z class (one round(z/res) per wave), the Morton part
+    // has a bit less per axis over the same extent (cells of 1/100 rad and 2/3 voxel)
+    if (h->zsplit) op = PfOrderParams{200.0, 1.5, 1.5, 1, h->P <= 65536 ? 4 : 5, 1, nullptr};
+    static const bool fixed_cells = getenv("SLAM_PF_ORDER_FIXED") != nullptr;    // (comparison: cells that do not follow the cloud)
+    if (!fixed_cells && h->ext_cur >= 0) op.ext = h->order_ext + PF_EXT_WORDS * h->ext_cur;
     // k_measure_box wants its workgroups' particles close in yaw (the box of a cluster grows with
     // range x yaw span): yaw-major keys, 1/400 rad and one-voxel cells
-    if (box_eligible(h)) op = PfOrderParams{400.0, 1.0, 1.0, 2, 4};
+    if (box_eligible(h)) op = PfOrderParams{400.0, 1.0, 1.0, 2, 4, 0, nullptr};
     if (const char* e = getenv("SLAM_PF_ORDER")) {
         double a, x, y; int m, b;
         if (sscanf(e, "%lf,%lf,%lf,%d,%d", &a, &x, &y, &m, &b) == 5 && (b == 4 || b == 5))
-            op = PfOrderParams{a, x, y, m, b};
+            op = PfOrderParams{a, x, y, m, b, (m == 1 && h->zsplit) ? 1 : 0, op.ext};
     }
     return op;
 }
@@ -1185,15 +1231,21 @@ int pf_measure(pf_handle* h, int add_points) {
     const bool mcols = !fuse && h->cfg.map_mode == PF_MAP_PER_PARTICLE && h->n_mcols > 0 && !h->force_exact_measure;
     if (!fuse && !mcols && !h->force_exact_measure && h->order_dirty) {
         Timed t(h, PF_K_ORDER);
+        // this ordering fills the extent record that is empty now and empties the other one (which the keys of
+        // these poses were made with)
+        const int ext_w = h->ext_cur < 0 ? 0 : h->ext_cur ^ 1;
         if (small_keys) {
-            HIP_TRY(h, pfk_order(h->stream, h->pose, h->P, h->order_keys, h->order_hist[0], h->order_hist[1],
-                                 h->order, h->sorted, op, h->hist_counted));
+            HIP_TRY(h, pfk_order(h->stream, h->pose, h->P, h->lanes, h->order_keys, h->order_hist[0], h->order_hist[1],
+                                 h->order, h->sorted, op, h->hist_counted, h->order_ext + PF_EXT_WORDS * ext_w,
+                                 h->order_ext + PF_EXT_WORDS * (ext_w ^ 1)));
         } else {
-            HIP_TRY(h, pfk_order(h->stream, h->pose, h->P, h->order_keys, h->order_hist[h->order_flip],
-                                 h->order_hist[h->order_flip ^ 1], h->order, h->sorted, op, false));
+            HIP_TRY(h, pfk_order(h->stream, h->pose, h->P, h->lanes, h->order_keys, h->order_hist[h->order_flip],
+                                 h->order_hist[h->order_flip ^ 1], h->order, h->sorted, op, false,
+                                 h->order_ext + PF_EXT_WORDS * ext_w, h->order_ext + PF_EXT_WORDS * (ext_w ^ 1)));
             h->order_flip ^= 1;
         }
         h->order_dirty = false;
+        h->ext_cur = ext_w;
     }
     h->hist_counted = false;           // consumed above, or stale: pfk_reduce_scores zeroes the pair
     HIP_TRY(h, wait_map_writes(h));      // the ordering above may overlap a running K5, K1 may not
@@ -1221,6 +1273,10 @@ int pf_measure(pf_handle* h, int add_points) {
             if (cch > (h->n_cols + 11) / 12) cch = (h->n_cols + 11) / 12;
             if (cch < 1) cch = 1;
             chunks = cch;
+            if (h->swz.kind == PF_LAYOUT_TILES)
+                HIP_TRY(h, pfk_measure_tile(h->stream, h->sorted, h->lanes, h->order, h->shadow, h->maps, h->swz, h->beams_tile, h->beams_col,
+                                            h->col_ends, h->lz_min, h->lz_max, chunks, grid_params(h), h->lmax_occ, h->partial));
+            else
             HIP_TRY(h, pfk_measure_col(h->stream, h->sorted, h->P, h->shadow, h->swz, h->beams_col, h->n_runs, h->col_ends,
                                        chunks, grid_params(h), h->lmax_occ, h->order, h->partial));
         }
@@ -1248,7 +1304,7 @@ int pf_measure(pf_handle* h, int add_points) {
     {
         Timed t(h, PF_K_ORDER);
         if (box || swz)
-            HIP_TRY(h, pfk_reduce_scores_l(h->stream, h->partial, chunks, h->P, h->order, h->scores, h->bmin,
+            HIP_TRY(h, pfk_reduce_scores_l(h->stream, h->partial, chunks, h->lanes, h->order, h->scores, h->bmin,
                                            h->order_hist[0], h->order_hist[1], small_keys ? 4096 : 0));
         else
         HIP_TRY(h, pfk_reduce_scores(h->stream, h->partial, chunks, h->P, h->scores, h->bmin, h->order_hist[0],
@@ -1312,7 +1368,7 @@ int pf_weights(pf_handle* h, const void* scores_global_dev) {
             r = rccl().AllGather(h->pose_src ? h->pose_src : h->pose, h->poses_all, PF_POSE_ROWS * (size_t)h->P,
                                  ncclFloat64, h->comm, h->stream);
         if (r == ncclSuccess && both)                 // and every rank's block minima of its scores (K3's min)
-            r = rccl().AllGather(h->bmin, h->bmin_all, ((size_t)h->P + 63) / 64, ncclInt32, h->comm, h->stream);
+            r = rccl().AllGather(h->bmin, h->bmin_all, (size_t)h->n_bmin, ncclInt32, h->comm, h->stream);
         if (both) { const ncclResult_t e = rccl().GroupEnd(); if (r == ncclSuccess) r = e; }
         gathered_bmin = both;
         if (r != ncclSuccess) return fail(h, PF_ERR_HIP, "pf_weights: ncclAllGather: %s", rccl().GetErrorString(r));
@@ -1322,7 +1378,7 @@ int pf_weights(pf_handle* h, const void* scores_global_dev) {
     {
         Timed t(h, PF_K_WEIGHTS);
         const int32_t* bmin = sc == h->scores && h->P == h->Pg ? h->bmin : gathered_bmin ? h->bmin_all : nullptr;
-        int n_bmin = gathered_bmin ? h->comm_world * ((h->P + 63) / 64) : 0;
+        int n_bmin = gathered_bmin ? h->comm_world * h->n_bmin : bmin ? h->n_bmin : 0;
         if (!bmin && !h->exact && h->Pg > 4096) {     // scores from the caller's own all-gather: a pass of block minima
             HIP_TRY(h, pfk_block_minima(h->stream, sc, h->Pg, h->bmin_ext));
             bmin = h->bmin_ext; n_bmin = pfk_block_minima_count(h->Pg);
@@ -1533,7 +1589,7 @@ int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const dou
         grid = h->maps; up.elements = h->elements; up.gy = h->cfg.grid_y; up.gz = h->cfg.grid_z;
         up.is_signed = 0;
         if (h->shadow && !h->shadow_dirty) {        // keep K1's gather-layout copy in step
-            up.shadow = h->shadow; up.swz_a = h->swz.a; up.swz_b = h->swz.b;
+            up.shadow = h->shadow; up.swz_a = h->swz.a; up.swz_b = h->swz.b; up.swz_kind = h->swz.kind;
         }
         NEED(h, p->hit_clamp >= 0 && p->hit_clamp <= 255 && p->miss_clamp >= 0 && p->miss_clamp <= 255, "clamps outside uint8");
     } else if (target == PF_GRID_LOCAL) {
@@ -1930,7 +1986,7 @@ int pf_comm_init(pf_handle* h, const void* id, int32_t rank, int32_t world) {
     h->comm_rank = rank;
     HIP_TRY(h, materialize_pose(h));
     HIP_TRY(h, dalloc(&h->scores_all, (size_t)h->Pg));
-    HIP_TRY(h, dalloc(&h->bmin_all, (size_t)world * (((size_t)h->P + 63) / 64)));
+    HIP_TRY(h, dalloc(&h->bmin_all, (size_t)world * (size_t)h->n_bmin));
     HIP_TRY(h, dalloc(&h->poses_all, PF_POSE_ROWS * (size_t)h->Pg));
     return PF_OK;
 }

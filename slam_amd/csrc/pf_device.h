@@ -19,6 +19,14 @@ __device__ __forceinline__ unsigned swz_col_addr(unsigned base, unsigned Z, unsi
 __device__ __forceinline__ unsigned swz_addr(unsigned X, unsigned Y, unsigned Z, unsigned a, unsigned b) {
     return swz_col_addr(swz_col_base(X, Y, a, b), Z, b);
 }
+// tile layout (PF_LAYOUT_TILES): Z*a + (Y/8 + 1)*b + (X/8 + 1)*64 + (X&7)*8 + (Y&7); the products stay below 2^32
+// (pf_create checks gz*a)
+__device__ __forceinline__ unsigned tile_addr(unsigned X, unsigned Y, unsigned Z, unsigned a, unsigned b) {
+    return Z * a + ((Y >> 3) + 1u) * b + ((((X >> 3) + 1u) << 6) | ((X & 7u) << 3) | (Y & 7u));
+}
+__device__ __forceinline__ unsigned layout_addr(unsigned X, unsigned Y, unsigned Z, unsigned a, unsigned b, unsigned kind) {
+    return kind == PF_LAYOUT_TILES ? tile_addr(X, Y, Z, a, b) : swz_addr(X, Y, Z, a, b);
+}
 
 
 // ------------------------------------------------------------------------------------------
@@ -64,7 +72,7 @@ __device__ inline void shadow_touch(const PfUpdateParams& up, long long f, int i
     const unsigned fu = (unsigned)f, gyz = (unsigned)(up.gy * up.gz);
     const unsigned xc = fu / gyz, r = fu - xc * gyz, yc = r / (unsigned)up.gz;
     const unsigned zc = r - yc * (unsigned)up.gz;
-    cell_touch(up.shadow, (long long)swz_addr(xc, yc, zc, up.swz_a, up.swz_b), inc, clampv, hit, false);
+    cell_touch(up.shadow, (long long)layout_addr(xc, yc, zc, up.swz_a, up.swz_b, up.swz_kind), inc, clampv, hit, false);
 }
 
 // S3P:632-661 for point i.

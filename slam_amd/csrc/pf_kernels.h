@@ -21,8 +21,15 @@ struct PfBeamF {
 // Gather layout of the shared grid ("bricks"): 4 x 4 x 4 cells per 64-B line, byte address of cell
 // (X, Y, Z) = ((X/4 * ny4 + Y/4) * nz4 + Z/4) * 64 + (X%4)*16 + (Y%4)*4 + Z%4 with ny4 = ceil(gy/4),
 // nz4 = ceil(gz/4); bytes = ceil(gx/4)*ny4*nz4*64. a = ny4*nz4*64, b = nz4*64.
+// kind 1 ("tiles", k_measure_tile): 8 x 8 cells of ONE z layer per 64-B line, z outermost, one tile of margin
+// around every layer (a 2 x 2-tile window that holds a cell of the grid never leaves the array): byte address
+// of cell (X, Y, Z) = Z*a + (Y/8 + 1)*b + (X/8 + 1)*64 + (X%8)*8 + Y%8 with b = ntx*64, a = nty*b,
+// ntx = ceil(gx/8) + 2, nty = ceil(gy/8) + 2; bytes = gz*a. The tiles (TX, TY), (TX+1, TY) are 128 contiguous bytes.
+#define PF_LAYOUT_BRICKS 0
+#define PF_LAYOUT_TILES 1
 struct PfSwz {
     uint32_t gx, gy, gz, a, b;
+    uint32_t kind;
 };
 // Up to four occupied beams of one local column (same lx, ly) for k_measure_col (32 B, one scalar
 // load): X, Y, the rounding test, the axis checks and the column's part of the address are per
@@ -95,27 +102,82 @@ struct PfOrderParams {
     double qa, qx, qy;   // cells per radian of yaw / per voxel of x / per voxel of y
     int32_t mode;        // 0: lexicographic yaw,x,y (6/4/5 bits)  1: Morton  2: yaw-major 8/2/2 bits
     int32_t bits;        // Morton: bits per axis, 4 (4096 buckets) or 5 (32768 buckets)
+    int32_t zsplit;      // 1 (Morton only): the top two key bits are round(z/res) & 3 (the z class), below them yaw with
+                         // `bits` bits and x, y with bits - 1 each; every class starts at a multiple of 64 lanes (holes:
+                         // order[] = -1), so a wave of k_measure_tile holds ONE value of round(z/res) unless the cloud
+                         // spans more than four of them
+    const int32_t* ext;  // (device, may be null) the extent of the cloud the last lane ordering saw: PF_EXT_WORDS ordered
+                         // ints = min, max of yaw, x/res, y/res (pf_ext_encode), word k at ext[k * PF_EXT_STRIDE]. When set and not empty, the cells are
+                         // sized so that the key's range covers 1.125 x that extent: the keys wrap, which is harmless
+                         // while the cloud is narrower than the range and puts far-apart particles into one wave when
+                         // it is not (fixed cells of 1/200 rad wrapped at 0.08 rad on the bench's cloud)
 };
+#define PF_EXT_STRIDE 32            // every word of the record on a 128-B line of its own (the atomics of a launch meet there)
+#define PF_EXT_WORDS (6 * PF_EXT_STRIDE)
+#define PF_ZCLASSES 4
 #ifdef __HIPCC__
 __device__ inline int pf_spread3(int v) {       // 5 bits -> every third bit
     return (v & 1) | ((v & 2) << 2) | ((v & 4) << 4) | ((v & 8) << 6) | ((v & 16) << 8);
 }
+// floats as ints whose signed order is the floats' (for atomicMin / atomicMax), and back
+__device__ inline int pf_ext_encode(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ inline float pf_ext_decode(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 // K1's lane-order key of particle i of a pose block with n columns
 __device__ inline int order_key(const double* __restrict__ pose, int n, int i, PfOrderParams op) {
+    if (op.ext) {                                   // cells from the last ordering's extent (wave-uniform loads)
+        const float a0 = pf_ext_decode(op.ext[0]), a1 = pf_ext_decode(op.ext[PF_EXT_STRIDE]);
+        const float x0 = pf_ext_decode(op.ext[2 * PF_EXT_STRIDE]), x1 = pf_ext_decode(op.ext[3 * PF_EXT_STRIDE]);
+        const float y0 = pf_ext_decode(op.ext[4 * PF_EXT_STRIDE]), y1 = pf_ext_decode(op.ext[5 * PF_EXT_STRIDE]);
+        if (a1 >= a0 && x1 >= x0 && y1 >= y0) {     // (not the empty record; NaN-free: the poses are validated)
+            const double na = (double)(1 << op.bits), nxy = (double)(1 << (op.zsplit ? op.bits - 1 : op.bits));
+            op.qa = na / fmax(1.125 * (double)(a1 - a0), na / op.qa * 0.25);     // never finer than a quarter of the
+            op.qx = nxy / fmax(1.125 * (double)(x1 - x0), nxy / op.qx * 0.25);   // default cells
+            op.qy = nxy / fmax(1.125 * (double)(y1 - y0), nxy / op.qy * 0.25);
+        }
+    }
     const int a = (int)floor(pose[3 * (size_t)n + i] * op.qa);
     const int x = (int)floor(pose[6 * (size_t)n + i] * op.qx);
     const int y = (int)floor(pose[7 * (size_t)n + i] * op.qy);
     if (op.mode == 0) return ((a & 63) << 9) | ((x & 15) << 5) | (y & 31);
     if (op.mode == 2) return ((a & 255) << 4) | ((x & 3) << 2) | (y & 3);      // yaw-major, 12 bits (k_measure_box)
+    if (op.zsplit) {
+        const int zc = (int)round(pose[8 * (size_t)n + i]) & (PF_ZCLASSES - 1);   // K1's zp (S3P:880 for z), wrapping
+        const int m = (1 << (op.bits - 1)) - 1;
+        return (zc << (3 * op.bits - 2)) | (((a >> (op.bits - 1)) & 1) << (3 * (op.bits - 1))) |
+               (pf_spread3(a & m) << 2) | (pf_spread3(x & m) << 1) | pf_spread3(y & m);
+    }
     const int m = (1 << op.bits) - 1;                                          // Morton
     return (pf_spread3(a & m) << 2) | (pf_spread3(x & m) << 1) | pf_spread3(y & m);
 }
 #endif
-// sorted: double [5][P] = cos, sin, x/res, y/res, z/res in lane order (K1's prologue).
+// sorted: double [5][lanes] = cos, sin, x/res, y/res, z/res in lane order (K1's prologue).
 // hist_counted: keys/hist were already filled for these poses (pfk_resample's fill stage).
-hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, int32_t* hist,
+// lanes: P, or with op.zsplit pfk_padded_lanes(P): order[] then has lanes entries, -1 in the holes.
+static inline int pfk_padded_lanes(int P) { return (P + 63) / 64 * 64 + PF_ZCLASSES * 64; }
+// ext_out / ext_reset (device, may be null): PF_EXT_WORDS ints each; the scatter stage folds the extent of these
+// poses into ext_out (which must hold the empty record on entry) and leaves the empty record in ext_reset.
+hipError_t pfk_order(hipStream_t st, const double* pose, int P, int lanes, int32_t* keys, int32_t* hist,
                      int32_t* next_hist, int32_t* order, double* sorted, PfOrderParams op,
-                     bool hist_counted);
+                     bool hist_counted, int32_t* ext_out = nullptr, int32_t* ext_reset = nullptr);
+// A column group for k_measure_tile (32 B, one s_load_dwordx8): the PfColG of the same index with, instead of
+// lz, the byte offset of each beam's z layer above the list's lowest one in the tile layout, lza[k] =
+// (lz[k] - lzmin) * a, which the kernel hands to the load as its scalar offset as it comes (the paths that
+// need lz itself read the PfColG list).
+struct __attribute__((aligned(32))) PfTileG {
+    float lx, ly;
+    uint32_t lza[4];
+    int32_t n, pad;
+};
+// K1 on the tile layout (shared grid only): one coalesced window load per beam and wave, every lane's byte
+// handed over by ds_bpermute (pf_measure_tile.hip). cg: plain column groups only (no run groups), sorted by
+// their number of beams: group_ends as for pfk_measure_col; lzmin, lzmax: the bounds of lz over the list.
+// lin: the same grid in the reference's order (the beams that leave the grid read it through the flat index).
+// lanes = pfk_padded_lanes(P), order/sorted from pfk_order with op.zsplit; partial: int2 [n_chunks][lanes]
+// in lane order.
+hipError_t pfk_measure_tile(hipStream_t st, const double* sorted, int lanes, const int32_t* order,
+                            const uint8_t* shadow, const uint8_t* lin, PfSwz sw, const PfTileG* cg, const PfColG* cgz, const int group_ends[4],
+                            int lzmin, int lzmax, int n_chunks, PfGridParams gp, double lmax, int2* partial);
+int pfk_tile_slot();     // column groups per trip of k_measure_tile (the unit its chunks are dealt in)
 // K1 on the gather layout (shared grid only), the beams grouped by column (PfColG): cg[0 .. n_runs) are
 // RUN groups (the occupied cells of one column inside an 8-cell z window: lz[0] = first z, lz[1], lz[2] =
 // a byte of 1 per occupied cell 0-3, 4-7, n = their number), then the plain groups sorted by their number
@@ -222,7 +284,7 @@ struct PfUpdateParams {
     int32_t hit_inc, hit_clamp, miss_inc, miss_clamp;
     int32_t is_signed;
     void* shadow;         // gather-layout copy of the shared grid to keep in step, or null
-    uint32_t swz_a, swz_b;
+    uint32_t swz_a, swz_b, swz_kind;
 };
 // One map update: M points (sensor frame) -> wpts (grid frame) and hits, then R rays.
 struct PfUpdateWork {

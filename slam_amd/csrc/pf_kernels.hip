@@ -593,6 +593,22 @@ __global__ __launch_bounds__(256) void k_swz_build(const uint8_t* __restrict__ l
     *(unsigned*)(shadow + swz_addr(X, Y, zq * 4u, sw.a, sw.b)) = w;
 }
 static unsigned swz_build_threads(PfSwz sw) { return (sw.gz + 3u) / 4u * sw.gx * sw.gy; }
+// reference order -> tile layout, one thread per dword (4 y-consecutive cells of one (X, Z)); consecutive
+// threads take consecutive Z of one (X, Y quad), so the four byte loads of a wave are contiguous runs
+__global__ __launch_bounds__(256) void k_tile_build(const uint8_t* __restrict__ lin,
+                                                    uint8_t* __restrict__ shadow, PfSwz sw) {
+    const unsigned long long o = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    const unsigned ny4 = (sw.gy + 3u) / 4u;
+    if (o >= (unsigned long long)sw.gx * ny4 * sw.gz) return;
+    const unsigned Z = (unsigned)(o % sw.gz);
+    const unsigned long long rem = o / sw.gz;              // X * ny4 + yq
+    const unsigned yq = (unsigned)(rem % ny4), X = (unsigned)(rem / ny4);
+    unsigned w = 0u;
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k)
+        if (yq * 4u + k < sw.gy) w |= (unsigned)lin[((size_t)X * sw.gy + yq * 4u + k) * sw.gz + Z] << (8u * k);
+    *(unsigned*)(shadow + tile_addr(X, yq * 4u, Z, sw.a, sw.b)) = w;
+}
 
 // One workgroup per 64 particles: wave q adds the chunks k = q, q+4, ... (a dozen independent loads
 // per lane, all in flight), wave 0 adds the four partial sums. Integer sums: any order.
@@ -706,6 +722,11 @@ hipError_t pfk_measure_col(hipStream_t st, const double* sorted, int P, const ui
     return hipGetLastError();
 }
 hipError_t pfk_swz_build(hipStream_t st, const uint8_t* lin, uint8_t* shadow, PfSwz sw) {
+    if (sw.kind == PF_LAYOUT_TILES) {
+        const unsigned long long nt = (unsigned long long)sw.gx * ((sw.gy + 3u) / 4u) * sw.gz;
+        hipLaunchKernelGGL(k_tile_build, dim3((unsigned)((nt + 255u) / 256u)), dim3(256), 0, st, lin, shadow, sw);
+        return hipGetLastError();
+    }
     const unsigned n = swz_build_threads(sw);
     hipLaunchKernelGGL(k_swz_build, dim3((n + 255u) / 256u), dim3(256), 0, st, lin, shadow, sw);
     return hipGetLastError();
@@ -728,9 +749,13 @@ __global__ __launch_bounds__(256) void k_order_hist(const double* __restrict__ p
 }
 // exclusive scan of hist[0 .. 1024*E) in place; zeroes the buffer the NEXT sort will count into.
 // One workgroup of 1024 threads, E = 4 or 32 consecutive entries per thread (int4 loads).
+// zsplit (E = 32 only): the PF_ZCLASSES z classes of 32768 / PF_ZCLASSES buckets each start at a multiple of 64 lanes: the pad in
+// front of a class is added to its buckets' offsets, and the holes of order[0 .. lanes) are set to -1.
 template <int E>
-__global__ __launch_bounds__(1024) void k_order_scan(int32_t* hist, int32_t* next_hist) {
+__global__ __launch_bounds__(1024) void k_order_scan(int32_t* hist, int32_t* next_hist, int P, int lanes, int zsplit,
+                                                     int32_t* __restrict__ order) {
     __shared__ int tot[16];
+    __shared__ int cstart[PF_ZCLASSES + 1], cpad[PF_ZCLASSES + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int4* h4 = (int4*)hist + (size_t)tid * (E / 4);
     int4* z4 = (int4*)next_hist + (size_t)tid * (E / 4);
@@ -750,6 +775,26 @@ __global__ __launch_bounds__(1024) void k_order_scan(int32_t* hist, int32_t* nex
     __syncthreads();
     int run = inc - sum;
     for (int k = 0; k < wv; ++k) run += tot[k];
+    int pad = 0;
+    if (zsplit) {                                  // (E = 32: thread TPC c holds the first bucket of class c)
+        constexpr int TPC = 1024 / PF_ZCLASSES;
+        if (tid % TPC == 0) cstart[tid / TPC] = run;
+        if (tid == 0) cstart[PF_ZCLASSES] = P;
+        __syncthreads();
+        if (tid == 0) {
+            int ps = 0;
+            for (int c = 0; c < PF_ZCLASSES; ++c) { cpad[c] = ps - cstart[c]; ps += (cstart[c + 1] - cstart[c] + 63) & ~63; }
+            cpad[PF_ZCLASSES] = ps - cstart[PF_ZCLASSES];
+        }
+        __syncthreads();
+        pad = cpad[tid / TPC];
+        // holes: behind class c's last lane up to the next class's first, and from the last class's end to lanes
+        for (int c = 0; c < PF_ZCLASSES; ++c) {
+            const int h0 = cstart[c + 1] + cpad[c], h1 = c < PF_ZCLASSES - 1 ? cstart[c + 1] + cpad[c + 1] : lanes;
+            for (int k = h0 + tid; k < h1; k += 1024) order[k] = -1;
+        }
+    }
+    run += pad;
 #pragma unroll
     for (int k = 0; k < E / 4; ++k) {
         int4 o;
@@ -761,30 +806,61 @@ __global__ __launch_bounds__(1024) void k_order_scan(int32_t* hist, int32_t* nex
         z4[k] = make_int4(0, 0, 0, 0);
     }
 }
+// The extent of the cloud (yaw, x/res, y/res) for the next key computation's cell sizes (PfOrderParams::ext):
+// wave minima and maxima, folded per workgroup in LDS, then one atomic per workgroup and word, every word on
+// a line of its own (one atomic per wave on six words of one line cost 10 us of the scatter kernel's 16);
+// workgroup 0 leaves the empty record in ext_reset. Call with all 256 threads.
+__device__ __forceinline__ void fold_extent(const double* __restrict__ pose, int P, int i, int32_t* ext_out,
+                                            int32_t* ext_reset) {
+    __shared__ int wext[4][6];
+    if (!ext_out) return;
+    if (ext_reset && blockIdx.x == 0 && threadIdx.x < 6) ext_reset[threadIdx.x * PF_EXT_STRIDE] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
+    const int ic = min(i, P - 1);
+    const float v[3] = {(float)pose[3 * (size_t)P + ic], (float)pose[6 * (size_t)P + ic], (float)pose[7 * (size_t)P + ic]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int lo = pf_ext_encode(v[k]), hi = lo;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+        if ((threadIdx.x & 63) == 0) { wext[threadIdx.x >> 6][2 * k] = lo; wext[threadIdx.x >> 6][2 * k + 1] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        int m = wext[0][k];
+        for (int w = 1; w < 4; ++w) m = (k & 1) ? max(m, wext[w][k]) : min(m, wext[w][k]);
+        if (k & 1) atomicMax(&ext_out[k * PF_EXT_STRIDE], m); else atomicMin(&ext_out[k * PF_EXT_STRIDE], m);
+    }
+}
 // Besides order[], writes the pose rows K1 needs (cos, sin, x/res, y/res, z/res) in lane order:
 // sorted: double [5][P], so that K1's prologue is five coalesced loads with no indirection.
-__global__ __launch_bounds__(256) void k_order_scatter(const int32_t* __restrict__ keys, int P,
+__global__ __launch_bounds__(256) void k_order_scatter(const int32_t* __restrict__ keys, int P, int lanes,
                                                        int32_t* hist, int32_t* __restrict__ order,
                                                        const double* __restrict__ pose,
-                                                       double* __restrict__ sorted) {
+                                                       double* __restrict__ sorted, int32_t* ext_out, int32_t* ext_reset) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    fold_extent(pose, P, i, ext_out, ext_reset);
     if (i >= P) return;
     const int r = atomicAdd(&hist[keys[i]], 1);
     order[r] = i;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) sorted[(size_t)k * P + r] = pose[(size_t)(4 + k) * P + i];
+    for (int k = 0; k < 5; ++k) sorted[(size_t)k * lanes + r] = pose[(size_t)(4 + k) * P + i];
 }
 // The 4096-bucket form of the last two stages in one launch: every workgroup scans the whole
 // histogram in LDS itself (16 KB, well under a launch boundary's cost), the position inside a
 // bucket comes from a second counter array `cursor`. hist and cursor are zeroed by
 // k_reduce_scores, which every pf_measure runs after K1.
-__global__ __launch_bounds__(256) void k_order_scatter_s(const int32_t* __restrict__ keys, int P,
+// zsplit: the PF_ZCLASSES z classes of 4096 / PF_ZCLASSES buckets each start at a multiple of 64 lanes (k_order_scan); workgroup 0
+// sets the holes of order[0 .. lanes) to -1.
+__global__ __launch_bounds__(256) void k_order_scatter_s(const int32_t* __restrict__ keys, int P, int lanes, int zsplit,
                                                          const int32_t* __restrict__ hist,
                                                          int32_t* cursor, int32_t* __restrict__ order,
                                                          const double* __restrict__ pose,
-                                                         double* __restrict__ sorted) {
+                                                         double* __restrict__ sorted, int32_t* ext_out, int32_t* ext_reset) {
     __shared__ int off[4096], lc[4096];
     __shared__ int tot[4];
+    __shared__ int cpad[PF_ZCLASSES + 1];
+    fold_extent(pose, P, blockIdx.x * 256 + threadIdx.x, ext_out, ext_reset);
     const int lt = threadIdx.x, lane = lt & 63, wv = lt >> 6;
     // everything this thread reads from memory first, so that the round trips overlap (loads do
     // not move up across the barriers below by themselves): its key, its five pose values, its
@@ -829,29 +905,47 @@ __global__ __launch_bounds__(256) void k_order_scatter_s(const int32_t* __restri
     if (i < P) rank = atomicAdd(&lc[key], 1);               // (lc was zeroed before the barrier above)
     __syncthreads();
     if (rank == 0) lc[key] = atomicAdd(&cursor[key], lc[key]);   // the only reader and writer of lc[key] here
+    constexpr int BPC = 4096 / PF_ZCLASSES;                      // buckets per z class
+    if (zsplit && lt == 0) {                                     // (off[] is complete since the barrier above)
+        int ps = 0;
+        for (int c = 0; c < PF_ZCLASSES; ++c) {
+            const int c0 = off[c * BPC], c1 = c < PF_ZCLASSES - 1 ? off[(c + 1) * BPC] : P;
+            cpad[c] = ps - c0;
+            ps += (c1 - c0 + 63) & ~63;
+        }
+        cpad[PF_ZCLASSES] = ps - P;
+    }
     __syncthreads();
+    if (zsplit && blockIdx.x == 0) {
+        for (int c = 0; c < PF_ZCLASSES; ++c) {
+            const int c1 = c < PF_ZCLASSES - 1 ? off[(c + 1) * BPC] : P;
+            const int h0 = c1 + cpad[c], h1 = c < PF_ZCLASSES - 1 ? c1 + cpad[c + 1] : lanes;
+            for (int k = h0 + lt; k < h1; k += 256) order[k] = -1;
+        }
+    }
     if (i >= P) return;
-    const int r = off[key] + lc[key] + rank;
+    const int r = off[key] + lc[key] + rank + (zsplit ? cpad[key / BPC] : 0);
     order[r] = i;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) sorted[(size_t)k * P + r] = row[k];
+    for (int k = 0; k < 5; ++k) sorted[(size_t)k * lanes + r] = row[k];
 }
 // hist_counted: hist/keys already hold this pose set's counts and keys (K4's fill stage made
 // them while it wrote the poses). 4096-bucket keys: hist = counts, next_hist = cursor, both left
 // for k_reduce_scores to zero; otherwise the three-launch form with alternating buffers.
-hipError_t pfk_order(hipStream_t st, const double* pose, int P, int32_t* keys, int32_t* hist,
+hipError_t pfk_order(hipStream_t st, const double* pose, int P, int lanes, int32_t* keys, int32_t* hist,
                      int32_t* next_hist, int32_t* order, double* sorted, PfOrderParams op,
-                     bool hist_counted) {
+                     bool hist_counted, int32_t* ext_out, int32_t* ext_reset) {
     const dim3 grid((P + 255) / 256);
+    const int zsplit = op.mode == 1 && op.zsplit ? 1 : 0;
     if (!hist_counted)
         hipLaunchKernelGGL(k_order_hist, grid, dim3(256), 0, st, pose, P, keys, hist, op);
     if (op.mode != 0 && op.bits == 4) {
-        hipLaunchKernelGGL(k_order_scatter_s, grid, dim3(256), 0, st, keys, P, hist, next_hist, order,
-                           pose, sorted);
+        hipLaunchKernelGGL(k_order_scatter_s, grid, dim3(256), 0, st, keys, P, lanes, zsplit, hist, next_hist, order,
+                           pose, sorted, ext_out, ext_reset);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_order_scan<32>, dim3(1), dim3(1024), 0, st, hist, next_hist);
-    hipLaunchKernelGGL(k_order_scatter, grid, dim3(256), 0, st, keys, P, hist, order, pose, sorted);
+    hipLaunchKernelGGL(k_order_scan<32>, dim3(1), dim3(1024), 0, st, hist, next_hist, P, lanes, zsplit, order);
+    hipLaunchKernelGGL(k_order_scatter, grid, dim3(256), 0, st, keys, P, lanes, hist, order, pose, sorted, ext_out, ext_reset);
     return hipGetLastError();
 }
 

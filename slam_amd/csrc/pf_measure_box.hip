@@ -418,8 +418,10 @@ __global__ __launch_bounds__(256) void k_reduce_scores_l(const int2* __restrict_
     if (q) return;
 #pragma unroll
     for (int r = 0; r < 3; ++r) { sx += sh[r][lane].x; sy += sh[r][lane].y; }
-    if (l < P) scores[order[l]] = make_int2(sx, sy);
-    int m = l < P ? sx : 0x7fffffff;
+    // (a hole of a padded lane order, order[] = -1, stands for no particle: k_measure_tile)
+    const int who = l < P ? order[l] : -1;
+    if (who >= 0) scores[who] = make_int2(sx, sy);
+    int m = who >= 0 ? sx : 0x7fffffff;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
     if (lane == 0) bmin[blockIdx.x] = m;

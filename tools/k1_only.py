@@ -15,7 +15,13 @@ cfg = capi.default_config(n_particles=P, map_mode=capi.PF_MAP_SHARED, grid_x=G, 
                           local_x=0, local_y=0, local_z=0, max_beams=max(M, 1))
 h = capi.Handle(cfg)
 h.write_map(0, sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"]); h.set_beams(*sc["beams"])
-for _ in range(reps):
+import numpy as np  # noqa: E402
+for k in range(reps):
+    # new poses every time, same cloud statistics: the lane ordering runs and sizes its cells by the last cloud
+    rng = np.random.default_rng(k)
+    tp = sc["true_pose"]
+    h.predict(tp[0] + rng.normal(0, 0.03, P), tp[1] + rng.normal(0, 0.03, P), tp[2] + rng.normal(0, 0.015, P),
+              tp[3] + rng.normal(0, 0.02, P))
     h.measure(0)
 h.synchronize()
 s, c = h.get_scores()

@@ -110,7 +110,11 @@ struct pf_handle {
     PfColG* beams_col = nullptr;       // [max_beams] the same grouped by local column (k_measure_col)
     PfTileG* beams_tile = nullptr;     // [max_beams] the same groups as k_measure_tile reads them
     std::vector<PfColG> h_cols, h_sort_tmp;
-    std::vector<PfTileG> h_tcols;      // h_cols as k_measure_tile reads them
+    std::vector<PfTileG> h_tcols;      // the column groups as k_measure_tile reads them (up to PF_TILE_GROUP beams each; h_cols then
+                                       // holds two PfColG per group: the lz of its beams 0-3 and 4-7)
+    struct TileGroupH { float lx, ly; int32_t n; int32_t lz[PF_TILE_GROUP]; };
+    std::vector<TileGroupH> h_tg, h_tg_tmp;
+    int tile_ends[PF_TILE_GROUP] = {0};   // ends of the groups with PF_TILE_GROUP, ..., 1 beams in beams_tile
     int lz_min = 0, lz_max = 0;        // bounds of lz over the occupied beams
     std::vector<unsigned long long> h_sort_keys;
     // k_measure_box: the same groups ordered by cluster, the clusters ordered by blockIdx.y group
@@ -736,7 +740,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
         CREATE_TRY(dalloc(&h->local, (size_t)round_up((unsigned long long)h->local_elements, 256)));
     {
         const size_t mb = (size_t)c.max_beams;
-        h->beam_blk_bytes = 64 * 9 + sizeof(PfBeam) * mb + sizeof(PfTileG) * (mb + 1) + sizeof(PfColG) * (mb + 1) + sizeof(PfBeam) * (mb + PF_BEAM_GROUP) +
+        h->beam_blk_bytes = 64 * 9 + sizeof(PfBeam) * mb + sizeof(PfTileG) * (mb + 1) + sizeof(PfColG) * 2 * (mb + 1) + sizeof(PfBeam) * (mb + PF_BEAM_GROUP) +
                             sizeof(PfBeamF) * (mb + PF_BEAM_GROUP) + sizeof(PfColG) * (mb + 1) + sizeof(PfCluster) * (mb + 1) +
                             sizeof(int) * 257;
         if (c.map_mode == PF_MAP_PER_PARTICLE)      // worst case, every beam a column of its own: 32 B + two units
@@ -1029,9 +1033,11 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     // groups with more beams first (k_measure_col's phases), and dealing a phase round-robin gives every
     // chunk the same share of it
     h->h_cols.clear();
+    h->h_tg.clear();
     std::vector<PfColG> runs;
     static const bool runs_wanted = !(getenv("SLAM_PF_RUNS") && atoi(getenv("SLAM_PF_RUNS")) == 0);
-    const bool use_runs = runs_wanted && !(h->shadow && h->swz.kind == PF_LAYOUT_TILES);   // (the tile kernel takes plain groups)
+    const bool tiles = h->shadow && h->swz.kind == PF_LAYOUT_TILES;
+    const bool use_runs = runs_wanted && !tiles;   // (the tile kernel takes plain groups)
     {
         std::vector<int32_t> zs, rest;
         for (int j = 0; j < n_real_occ;) {
@@ -1062,6 +1068,15 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
                 } else {
                     rest.push_back(zs[i++]);
                 }
+            }
+            if (tiles) {                                             // k_measure_tile: up to PF_TILE_GROUP beams of a column per group
+                for (size_t i = 0; i < rest.size(); i += PF_TILE_GROUP) {
+                    pf_handle::TileGroupH g{};
+                    g.lx = (float)b0.lx; g.ly = (float)b0.ly; g.n = (int32_t)std::min<size_t>(PF_TILE_GROUP, rest.size() - i);
+                    for (int k = 0; k < PF_TILE_GROUP; ++k) g.lz[k] = rest[std::min(i + (size_t)k, rest.size() - 1)];
+                    h->h_tg.push_back(g);
+                }
+                continue;
             }
             for (size_t i = 0; i < rest.size(); i += 4) {
                 PfColG g{};
@@ -1109,19 +1124,47 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
             h->col_ends[4 - n] = e;
         }
     }
-    const bool tiles = h->shadow && h->swz.kind == PF_LAYOUT_TILES;
     if (tiles) {
+        // groups with more beams first, inside a count the farthest first (as above), through 64-bit keys
+        std::vector<pf_handle::TileGroupH>& tg = h->h_tg;
+        h->h_sort_keys.resize(tg.size());
+        for (size_t i = 0; i < tg.size(); ++i) {
+            const long long lx = (long long)tg[i].lx, ly = (long long)tg[i].ly;
+            const unsigned long long r2 = std::min<unsigned long long>((unsigned long long)(lx * lx + ly * ly) >> 3, (1ull << 36) - 1);
+            h->h_sort_keys[i] = ((unsigned long long)(PF_TILE_GROUP - tg[i].n) << 60) | (((1ull << 36) - 1 - r2) << 24) | (unsigned long long)(i & 0xffffff);
+        }
+        if (tg.size() < (1u << 24)) {
+            std::sort(h->h_sort_keys.begin(), h->h_sort_keys.end());
+            h->h_tg_tmp.resize(tg.size());
+            for (size_t i = 0; i < tg.size(); ++i) h->h_tg_tmp[i] = tg[(size_t)(h->h_sort_keys[i] & 0xffffff)];
+            tg.swap(h->h_tg_tmp);
+        } else {
+            std::stable_sort(tg.begin(), tg.end(), [](const pf_handle::TileGroupH& a, const pf_handle::TileGroupH& b) { return a.n > b.n; });
+        }
         int zmin = INT32_MAX, zmax = INT32_MIN;
-        for (const PfColG& g : h->h_cols) { zmin = std::min(zmin, g.lz[0]); zmax = std::max(zmax, g.lz[g.n - 1]); }
-        if (h->h_cols.empty()) zmin = zmax = 0;
+        for (const auto& g : tg) { zmin = std::min(zmin, g.lz[0]); zmax = std::max(zmax, g.lz[g.n - 1]); }
+        if (tg.empty()) zmin = zmax = 0;
         h->lz_min = zmin; h->lz_max = zmax;
-        h->h_tcols.resize(h->h_cols.size());
-        for (size_t i = 0; i < h->h_cols.size(); ++i) {
-            const PfColG& g = h->h_cols[i];
+        h->h_tcols.resize(tg.size());
+        h->h_cols.resize(2 * tg.size());
+        for (size_t i = 0; i < tg.size(); ++i) {
+            const auto& g = tg[i];
             PfTileG t{};
             t.lx = g.lx; t.ly = g.ly; t.n = g.n;
-            for (int k = 0; k < 4; ++k) t.lza[k] = (uint32_t)(g.lz[k] - zmin) * h->swz.a;   // (mod 2^32: used only when the layer is inside the grid)
+            for (int k = 0; k < PF_TILE_GROUP; ++k) t.lza[k] = (uint32_t)(g.lz[k] - zmin) * h->swz.a;   // (mod 2^32: used only when the layer is inside the grid)
             h->h_tcols[i] = t;
+            for (int half = 0; half < 2; ++half) {
+                PfColG c{};
+                c.lx = g.lx; c.ly = g.ly; c.n = std::max(0, std::min(4, g.n - 4 * half));
+                for (int k = 0; k < 4; ++k) c.lz[k] = g.lz[4 * half + k];
+                h->h_cols[2 * i + (size_t)half] = c;
+            }
+        }
+        h->n_cols = (int)tg.size();
+        int e = 0;
+        for (int n = PF_TILE_GROUP; n >= 1; --n) {
+            while (e < h->n_cols && tg[(size_t)e].n == n) ++e;
+            h->tile_ends[PF_TILE_GROUP - n] = e;
         }
     }
     // everything goes through one pinned, double-buffered block: the call does not wait for the stream
@@ -1275,7 +1318,7 @@ int pf_measure(pf_handle* h, int add_points) {
             chunks = cch;
             if (h->swz.kind == PF_LAYOUT_TILES)
                 HIP_TRY(h, pfk_measure_tile(h->stream, h->sorted, h->lanes, h->order, h->shadow, h->maps, h->swz, h->beams_tile, h->beams_col,
-                                            h->col_ends, h->lz_min, h->lz_max, chunks, grid_params(h), h->lmax_occ, h->partial));
+                                            h->tile_ends, h->lz_min, h->lz_max, chunks, grid_params(h), h->lmax_occ, h->partial));
             else
             HIP_TRY(h, pfk_measure_col(h->stream, h->sorted, h->P, h->shadow, h->swz, h->beams_col, h->n_runs, h->col_ends,
                                        chunks, grid_params(h), h->lmax_occ, h->order, h->partial));

@@ -159,23 +159,26 @@ static inline int pfk_padded_lanes(int P) { return (P + 63) / 64 * 64 + PF_ZCLAS
 hipError_t pfk_order(hipStream_t st, const double* pose, int P, int lanes, int32_t* keys, int32_t* hist,
                      int32_t* next_hist, int32_t* order, double* sorted, PfOrderParams op,
                      bool hist_counted, int32_t* ext_out = nullptr, int32_t* ext_reset = nullptr);
-// A column group for k_measure_tile (32 B, one s_load_dwordx8): the PfColG of the same index with, instead of
-// lz, the byte offset of each beam's z layer above the list's lowest one in the tile layout, lza[k] =
-// (lz[k] - lzmin) * a, which the kernel hands to the load as its scalar offset as it comes (the paths that
-// need lz itself read the PfColG list).
-struct __attribute__((aligned(32))) PfTileG {
+// A column group for k_measure_tile (64 B): up to PF_TILE_GROUP occupied beams of one local column, and instead
+// of their lz the byte offset of each beam's z layer above the list's lowest one in the tile layout, lza[k] =
+// (lz[k] - lzmin) * a, which the kernel hands to the load as its scalar offset as it comes. The paths that need
+// lz itself read it from a PfColG list with two entries per group (beams 0-3 and 4-7).
+#define PF_TILE_GROUP 8
+struct __attribute__((aligned(64))) PfTileG {
     float lx, ly;
-    uint32_t lza[4];
     int32_t n, pad;
+    uint32_t lza[PF_TILE_GROUP];
+    int32_t pad1[4];
 };
 // K1 on the tile layout (shared grid only): one coalesced window load per beam and wave, every lane's byte
-// handed over by ds_bpermute (pf_measure_tile.hip). cg: plain column groups only (no run groups), sorted by
-// their number of beams: group_ends as for pfk_measure_col; lzmin, lzmax: the bounds of lz over the list.
+// handed over by ds_bpermute (pf_measure_tile.hip). cg: the column groups sorted by their number of beams,
+// group_ends[k] = end of the groups with PF_TILE_GROUP - k beams; cgz: their lz (two PfColG per group); lzmin,
+// lzmax: the bounds of lz over the list.
 // lin: the same grid in the reference's order (the beams that leave the grid read it through the flat index).
 // lanes = pfk_padded_lanes(P), order/sorted from pfk_order with op.zsplit; partial: int2 [n_chunks][lanes]
 // in lane order.
 hipError_t pfk_measure_tile(hipStream_t st, const double* sorted, int lanes, const int32_t* order,
-                            const uint8_t* shadow, const uint8_t* lin, PfSwz sw, const PfTileG* cg, const PfColG* cgz, const int group_ends[4],
+                            const uint8_t* shadow, const uint8_t* lin, PfSwz sw, const PfTileG* cg, const PfColG* cgz, const int group_ends[PF_TILE_GROUP],
                             int lzmin, int lzmax, int n_chunks, PfGridParams gp, double lmax, int2* partial);
 int pfk_tile_slot();     // column groups per trip of k_measure_tile (the unit its chunks are dealt in)
 // K1 on the gather layout (shared grid only), the beams grouped by column (PfColG): cg[0 .. n_runs) are

@@ -37,7 +37,10 @@
 #define TILE_EXP 0      // development: 1 no window loads, 2 no ds_bpermute, 3 neither (wrong results, timing only)
 #endif
 #ifndef TILE_T
-#define TILE_T 3        // column groups per trip (their loads are in flight together; 2: 27.6, 3: 26.3, 4: 30.0 us at configs[1])
+#define TILE_T 3        // column groups per trip for groups of up to four beams (their loads are in flight together; 2: 27.6,
+#endif                  // 3: 26.3, 4: 30.0 us at configs[1] with groups of at most four)
+#ifndef TILE_T8
+#define TILE_T8 2       // ... for groups of five to eight beams
 #endif
 namespace {
 
@@ -197,30 +200,32 @@ __device__ __forceinline__ void tile_trip(const PfTileG* __restrict__ cg, const 
     } else {
         const double tz = sorted[4 * (size_t)lanes + L.rd];
 #pragma unroll
-        for (int k = 0; k < N; ++k) tile_beam_generic(X[0], Y[0], cgz[g].lz[k], tz, gp, lin, sum, cnt);
+        for (int k = 0; k < N; ++k) tile_beam_generic(X[0], Y[0], cgz[2 * g + (k >> 2)].lz[k & 3], tz, gp, lin, sum, cnt);
     }
 }
 
-// One phase: the groups [g0, g1) all have N beams. Slot pp = groups TILE_T pp .. TILE_T pp + TILE_T - 1 of the
-// whole list belongs to chunk pp % gridDim.y, across the phase boundaries (k_measure_col's dealing: every chunk
-// gets the same number of beams to within one slot; a slot that straddles a phase boundary is walked group by
-// group by each of the phases it touches, every group exactly once).
+// One phase: the groups [g0, g1) all have N beams and go T = tile_t(N) to a trip. The trips of the whole list are
+// numbered through (slot0 = the number of this phase's first trip) and trip j belongs to chunk j % gridDim.y, so
+// every chunk gets the same number of trips of every size to within one; a phase's last trip may be short and is
+// then walked group by group.
+__host__ __device__ constexpr int tile_t(int N) { return N > 4 ? TILE_T8 : TILE_T; }
 template <int N, bool STATS>
-__device__ __forceinline__ void tile_phase(const PfTileG* __restrict__ cg, const PfColG* __restrict__ cgz, int g0, int g1, const TileLane& L,
-                                           const TileGrid& G, const PfGridParams& gp,
+__device__ __forceinline__ void tile_phase(const PfTileG* __restrict__ cg, const PfColG* __restrict__ cgz, int g0, int g1, int& slot0,
+                                           const TileLane& L, const TileGrid& G, const PfGridParams& gp,
                                            const uint8_t* __restrict__ lin, __amdgpu_buffer_rsrc_t rsrc,
                                            const double* __restrict__ sorted, int lanes,
                                            int al, bool coop_ok, int& sum, int& cnt, unsigned (&st)[4],
                                            unsigned long long* __restrict__ stats) {
+    constexpr int T = tile_t(N);
     const int C = (int)gridDim.y, y = (int)blockIdx.y;
-    int pp = g0 / TILE_T;
-    pp += (y - pp % C + C) % C;
-    for (; TILE_T * pp < g1; pp += C) {
-        const int ga = max(TILE_T * pp, g0), gb = min(TILE_T * pp + TILE_T, g1);
-        if (gb - ga == TILE_T) tile_trip<N, TILE_T, STATS>(cg, cgz, ga, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats);
+    const int nslots = (g1 - g0 + T - 1) / T;
+    for (int sl = (y - slot0 % C + C) % C; sl < nslots; sl += C) {
+        const int ga = g0 + sl * T, gb = min(ga + T, g1);
+        if (gb - ga == T) tile_trip<N, T, STATS>(cg, cgz, ga, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats);
         else
             for (int g = ga; g < gb; ++g) tile_trip<N, 1, STATS>(cg, cgz, g, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats);
     }
+    slot0 += nslots;
 }
 
 // STATS (SLAM_PF_TILE_STATS=1, development aid): stats[0..3] += wave-beams by window load / the other ways / of groups
@@ -228,7 +233,7 @@ __device__ __forceinline__ void tile_phase(const PfTileG* __restrict__ cg, const
 template <bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_measure_tile(
         const double* __restrict__ sorted, int lanes, const int32_t* __restrict__ order,
-        const uint8_t* __restrict__ shadow, const uint8_t* __restrict__ lin, PfSwz sw, const PfTileG* __restrict__ cg, const PfColG* __restrict__ cgz, int4 ends, int lzmin, int lzmax,
+        const uint8_t* __restrict__ shadow, const uint8_t* __restrict__ lin, PfSwz sw, const PfTileG* __restrict__ cg, const PfColG* __restrict__ cgz, int4 ends, int4 ends2, int lzmin, int lzmax,
         PfGridParams gp, double lmax, int2* __restrict__ partial, unsigned long long* __restrict__ stats) {
     __builtin_amdgcn_s_setprio(3);
     const int lane_id = blockIdx.x * 256 + threadIdx.x;
@@ -259,8 +264,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // the texture path takes a linear 128-B run at half the cycles of a permuted one (tools/ubench_gather6.hip: 7.8-9.0
     // CU-cycles per wave-instruction against 17)
     L.lanez = (int)((l >> 5) * sw.b + (l & 31u) * 4u) + G.zoff;
-    // the anchor lane: the one nearest the wave's mean pose (its cell is near the middle of the wave's cells for
-    // every beam, the map from pose to cell being affine up to rounding); distance in voxels at half the list's range
+    // the anchor lane: the middle one of the wave in the lane order's curve (TILE_ANCHOR_MEAN: the lane nearest the
+    // wave's mean pose instead, four wave reductions: no more groups take the window loads that way)
+#ifdef TILE_ANCHOR_MEAN
     int al;
     {
         float mx = (float)tx, my = (float)ty, mq = sf;
@@ -273,19 +279,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o, 64));
         al = __builtin_amdgcn_readfirstlane((int)(key & 63u));
     }
+#else
+    const int al = 31;
+#endif
     // raw buffer over the whole copy (stride 0)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)shadow, 0, (int)(sw.gz * sw.a), 0x00020000);
     int sum = 0, cnt = 0;
     unsigned st[4] = {0, 0, 0, 0};
     // priority follows progress (k_measure_col: the issue arbiter favours the oldest wave, which staggers the
     // finish times of a launch that is one residency deep)
-    tile_phase<4, STATS>(cg, cgz, 0, ends.x, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats);
+    int slot0 = 0;
+#define TILE_PHASE(N, G0, G1) tile_phase<N, STATS>(cg, cgz, G0, G1, slot0, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats)
+    TILE_PHASE(8, 0, ends.x);
+    TILE_PHASE(7, ends.x, ends.y);
+    TILE_PHASE(6, ends.y, ends.z);
+    TILE_PHASE(5, ends.z, ends.w);
     __builtin_amdgcn_s_setprio(2);
-    tile_phase<3, STATS>(cg, cgz, ends.x, ends.y, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats);
+    TILE_PHASE(4, ends.w, ends2.x);
+    TILE_PHASE(3, ends2.x, ends2.y);
     __builtin_amdgcn_s_setprio(1);
-    tile_phase<2, STATS>(cg, cgz, ends.y, ends.z, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats);
+    TILE_PHASE(2, ends2.y, ends2.z);
     __builtin_amdgcn_s_setprio(0);
-    tile_phase<1, STATS>(cg, cgz, ends.z, ends.w, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats);
+    TILE_PHASE(1, ends2.z, ends2.w);
+#undef TILE_PHASE
     // in lane order (coalesced); pfk_reduce_scores_l sends the sums to the particles through order[]
     if (who >= 0) partial[(size_t)blockIdx.y * lanes + lane_id] = make_int2(sum, cnt);
     if (STATS && (threadIdx.x & 63) == 0) {
@@ -297,18 +313,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 }  // namespace
 
 int pfk_tile_slot() { return TILE_T; }
+static_assert(PF_TILE_GROUP == 8, "k_measure_tile has eight phases");
 
 hipError_t pfk_measure_tile(hipStream_t st, const double* sorted, int lanes, const int32_t* order,
-                            const uint8_t* shadow, const uint8_t* lin, PfSwz sw, const PfTileG* cg, const PfColG* cgz, const int group_ends[4],
+                            const uint8_t* shadow, const uint8_t* lin, PfSwz sw, const PfTileG* cg, const PfColG* cgz, const int group_ends[PF_TILE_GROUP],
                             int lzmin, int lzmax, int n_chunks, PfGridParams gp, double lmax, int2* partial) {
     static const bool want_stats = getenv("SLAM_PF_TILE_STATS") != nullptr;
     const dim3 grid((lanes + 255) / 256, n_chunks);
     const int4 ends = make_int4(group_ends[0], group_ends[1], group_ends[2], group_ends[3]);
+    const int4 ends2 = make_int4(group_ends[4], group_ends[5], group_ends[6], group_ends[7]);
     if (want_stats) {
         unsigned long long* stats = nullptr;
         if (hipMalloc((void**)&stats, 256) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(stats, 0, 256, st);
-        hipLaunchKernelGGL(k_measure_tile<true>, grid, dim3(256), 0, st, sorted, lanes, order, shadow, lin, sw, cg, cgz, ends, lzmin,
+        hipLaunchKernelGGL(k_measure_tile<true>, grid, dim3(256), 0, st, sorted, lanes, order, shadow, lin, sw, cg, cgz, ends, ends2, lzmin,
                            lzmax, gp, lmax, partial, stats);
         unsigned long long hs[32];
         (void)hipStreamSynchronize(st);
@@ -321,7 +339,7 @@ hipError_t pfk_measure_tile(hipStream_t st, const double* sorted, int lanes, con
         fprintf(stderr, "\n");
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_measure_tile<false>, grid, dim3(256), 0, st, sorted, lanes, order, shadow, lin, sw, cg, cgz, ends, lzmin,
+    hipLaunchKernelGGL(k_measure_tile<false>, grid, dim3(256), 0, st, sorted, lanes, order, shadow, lin, sw, cg, cgz, ends, ends2, lzmin,
                        lzmax, gp, lmax, partial, (unsigned long long*)nullptr);
     return hipGetLastError();
 }

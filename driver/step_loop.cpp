@@ -185,7 +185,7 @@ int main(int argc, char** argv) {
     std::vector<double> x((size_t)P, 7.5), y((size_t)P, 7.5), z((size_t)P, 1.5), yaw((size_t)P, 0.0), u((size_t)P);
     std::vector<float> noise(4 * (size_t)P);
     std::vector<uint8_t> img;
-    std::vector<double> cloud(3 * (size_t)npix), sample(3 * 500);
+    std::vector<double> cloud(3 * ((size_t)npix + 1)), sample(3 * 500);   // one row more: the reference's draws are inclusive of n (S3P:317, 666) and a replay may name it
     std::vector<int32_t> pick(500), ray_idx(2400);
     // members of class Slam (S3P:56-61, 265-283, 823-825)
     double local_pos[3] = {5, 5, 1.5}, local_yaw = 0;

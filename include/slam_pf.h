@@ -234,6 +234,13 @@ int pf_scan_vote_static(int32_t device, void* hip_stream, const uint8_t* grid_de
                         const double pos[3], const double zyx[3], int32_t n_yaw, int32_t yaw_k0,
                         int32_t yaw_kstep, int32_t n_t, double length, int32_t* sums_dev);
 
+/* Set-up half of pf_scan_vote_static (no counterpart in the reference either): takes the address of `device`'s
+ * copy of the scratch array (hipGetSymbolAddress: a code-object load and a symbol look-up, which may allocate
+ * inside the runtime and must not run under stream capture). Call it once per device before the first
+ * pf_scan_vote_static there; without it that first call does the look-up itself. Both calls leave the caller's
+ * current device as it was. */
+int pf_scan_vote_static_warmup(int32_t device);
+
 /* ---- plumbing ------------------------------------------------------------------------------ */
 void* pf_stream(pf_handle* h);                           /* the hipStream_t the handle works on */
 /* ---- keyframe ring of the localisation grid: S3P:286-289, 305-312, 419-529 -------------------

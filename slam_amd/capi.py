@@ -29,7 +29,7 @@ SYMBOLS = (
     "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init "
     "pf_ring_default_params pf_ring_init pf_ring_paint pf_ring_update pf_ring_state "
     "pf_depth_to_cloud pf_read_occupied pf_sequential_cdf pfh_draw_indices pfh_vote_epilogue pfh_pose_message pfh_migration_plan "
-    "pfh_update_realtime_pos pf_set_best_index pf_scan_vote_static").split()
+    "pfh_update_realtime_pos pf_set_best_index pf_scan_vote_static pf_scan_vote_static_warmup").split()
 
 
 class Config(C.Structure):
@@ -505,6 +505,13 @@ def scan_vote_static(device, stream, grid_ptr, dims, resolution, points_ptr, n_p
                                    C.c_void_p(sums_ptr))
     if rc != PF_OK:
         raise PfError(f"pf_scan_vote_static -> {rc}: {lib().pf_last_error(None).decode()}")
+
+
+def scan_vote_static_warmup(device):
+    """pf_scan_vote_static_warmup: the one-time set-up of pf_scan_vote_static on a device (outside any capture)."""
+    rc = lib().pf_scan_vote_static_warmup(C.c_int32(device))
+    if rc != PF_OK:
+        raise PfError(f"pf_scan_vote_static_warmup -> {rc}: {lib().pf_last_error(None).decode()}")
 
 
 def comm_unique_id():

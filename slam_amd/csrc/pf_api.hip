@@ -985,6 +985,11 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
     if (!h) return PF_ERR_ARG;
     NEED(h, n >= 0 && n <= h->cfg.max_beams, "n_beams beyond max_beams");
     NEED(h, n == 0 || (bx && by && bz && bv), "null beam array");
+    // the whole input is checked before any state of the handle is touched: a refused call leaves the resident
+    // lists and their host copies as they were (the lazy lists were uploaded from clobbered vectors)
+    for (int64_t j = 0; j < n; ++j)
+        if ((uint32_t)(bx[j] + (1 << 20)) > (2u << 20) || (uint32_t)(by[j] + (1 << 20)) > (2u << 20) || (uint32_t)(bz[j] + (1 << 20)) > (2u << 20))
+            return fail(h, PF_ERR_ARG, "pf_set_beams: beam %lld offset beyond +-2^20 voxels", (long long)j);
     h->h_beams.resize((size_t)n);
     h->h_beams_occ.resize((size_t)n + PF_BEAM_GROUP); h->h_beams_occ_f.resize((size_t)n + PF_BEAM_GROUP);
     int n_real_occ = 0;
@@ -996,8 +1001,6 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         const int thr = h->cfg.occ_threshold;
         for (int64_t j = 0; j < n; ++j) {
             const int32_t X = bx[j], Y = by[j], Z = bz[j];
-            if ((uint32_t)(X + (1 << 20)) > (2u << 20) || (uint32_t)(Y + (1 << 20)) > (2u << 20) || (uint32_t)(Z + (1 << 20)) > (2u << 20))
-                return fail(h, PF_ERR_ARG, "pf_set_beams: beam %lld offset beyond +-2^20 voxels", (long long)j);
             PfBeam b;
             b.lx = (double)X; b.ly = (double)Y; b.lz = (double)Z;               // S3P:745-747 int->double
             b.v = bv[j]; b.pad = 0;

@@ -63,6 +63,24 @@ __global__ __launch_bounds__(256) void k_vote_setup(VoteSetup s, double* __restr
 
 }  // namespace
 
+// Resolves this GPU's copy of the scratch array (a code-object load and a symbol look-up on the first call per
+// device, which may allocate inside the runtime and is not allowed under stream capture): call it once per device
+// at set-up, outside any capture; pf_scan_vote_static then only launches kernels.
+extern "C" int pf_scan_vote_static_warmup(int32_t device) {
+    if (device < 0 || device >= kMaxDevices) { pfk_set_global_error("pf_scan_vote_static_warmup: device ordinal outside [0, 64)"); return PF_ERR_ARG; }
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);
+    hipError_t e = prev_device == device ? hipSuccess : hipSetDevice(device);
+    unsigned char* base = nullptr;
+    if (e == hipSuccess) e = scratch_ptr(device, &base);
+    if (prev_device >= 0 && prev_device != device) (void)hipSetDevice(prev_device);
+    if (e != hipSuccess) {
+        pfk_set_global_error(hipGetErrorString(e));
+        return e == hipErrorInvalidDevice || e == hipErrorNoDevice ? PF_ERR_NODEVICE : PF_ERR_HIP;
+    }
+    return PF_OK;
+}
+
 extern "C" int pf_scan_vote_static(int32_t device, void* hip_stream, const uint8_t* grid_dev, int32_t gx,
                                    int32_t gy, int32_t gz, double resolution, const double* points_dev,
                                    int64_t n_points, const double pos[3], const double zyx[3], int32_t n_yaw,
@@ -80,7 +98,11 @@ extern "C" int pf_scan_vote_static(int32_t device, void* hip_stream, const uint8
     REJECT(!(resolution > 0.0) || !isfinite(resolution) || !isfinite(length), "resolution / length");
     for (int k = 0; k < 3; ++k) REJECT(!isfinite(pos[k]) || fabs(pos[k]) >= 1e6 || !isfinite(zyx[k]), "pose not finite");
 #undef REJECT
-    hipError_t e = hipSetDevice(device);
+    // the caller's current device is put back before returning
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev_device == device ? -1 : prev_device};
+    hipError_t e = prev_device == device ? hipSuccess : hipSetDevice(device);
     unsigned char* base = nullptr;
     if (e == hipSuccess) e = scratch_ptr(device, &base);
     if (e != hipSuccess) {

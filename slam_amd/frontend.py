@@ -27,8 +27,11 @@ N_RAYS = 2400                                                        # S3P:668
 
 class FrameLoop:
     def __init__(self, loc, mapper, width=640, height=480, pool=4, focal=385.0 / 4.0, resolution=0.05,
-                 map_size=(10, 10, 4)):
+                 map_size=(10, 10, 4), replay=False):
         self.loc, self.mapper = loc, mapper
+        # replay: the index draws keep the reference's inclusive upper bound n (S3P:317, 666), for seeds known not to
+        # draw it (the golden fixtures); default: draws in [0, n-1], which any seed serves
+        self.replay = replay
         self.width, self.height, self.pool, self.focal = width, height, pool, focal
         self.resolution = resolution
         half = [map_size[0] // 2, map_size[1] // 2, map_size[2] // 2]   # S3P:269-271: integer halves
@@ -73,7 +76,9 @@ class FrameLoop:
     def scan_localization(self, seed):
         self.rot_y, self.rot_x = float(self.gyr_zyx[1]), float(self.gyr_zyx[2])      # S3P:301-302
         self.loc.ring_paint()                                                        # S3P:305-312
-        pick = capi.draw_indices(seed, N_SCAN_POINTS, self.n)                        # S3P:315-319, inclusive
+        # S3P:315-319 draws in [0, n] inclusive, one row past the cloud; replay=True keeps that (fixture seeds are
+        # screened so that row n is never drawn); otherwise the draw is in [0, n-1] like driver/step_loop.cpp's
+        pick = capi.draw_indices(seed, N_SCAN_POINTS, self.n if self.replay else self.n - 1)
         sample = self.cloud[pick]                                                    # S3P:320-322
         zyx = (self.yaw_scan, self.rot_y, self.rot_x)
         _, best = self.loc.scan_vote(sample, self.pos_scan, zyx, **VOTE)             # S3P:328-376
@@ -96,10 +101,10 @@ class FrameLoop:
     def build_local_map(self, seed):
         self.local_pos = self.local_pos + self.pos_diff_scan                         # S3P:623-625
         self.local_yaw = self.local_yaw + self.yaw_diff                              # S3P:626
-        rays = capi.draw_indices(seed, N_RAYS, self.n)                               # S3P:664-669, inclusive
+        rays = capi.draw_indices(seed, N_RAYS, self.n if self.replay else self.n - 1)   # S3P:664-669 (inclusive in replay)
         if np.any(rays >= self.n):
-            raise ValueError("a ray index names the row behind the cloud (S3P:666 draws it; the "
-                             "reference then marches to a stale point): draw in [0, n-1]")
+            raise ValueError("a ray index names the row behind the cloud (S3P:666 draws it; the reference then "
+                             "marches to a stale point): replay=True is for seeds screened against that")
         self.mapper.set_scan(self.cloud[:self.n], rays)
         self.mapper.update_map(capi.PF_GRID_LOCAL, self.update_params, self.local_pos,
                                (self.local_yaw, self.rot_y, self.rot_x))             # S3P:628-704

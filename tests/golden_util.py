@@ -53,7 +53,7 @@ def check_vote_cases(golden_dir, make_loc, fixture="vote.npz", at_least=10):
         loc = make_loc()
         grid = np.zeros(NL, np.uint8); grid[g[name + "_grid_idx"]] = 1
         loc.write_map(0, grid)
-        fl = FrameLoop(loc, None)
+        fl = FrameLoop(loc, None, replay=True)
         before, after = g[name + "_before"], g[name + "_after"]
         cloud = cloud_of(g[name + "_cloud_mm"])
         fl.n = len(cloud); fl.cloud[:fl.n] = cloud
@@ -81,7 +81,7 @@ def check_local_map_cases(golden_dir, make_mapper, fixture="local_map.npz", at_l
         mapper = make_mapper()
         pre = pre_map(int(g[name + "_pre_k"]))
         mapper.write_local_map(pre)
-        fl = FrameLoop(None, mapper)
+        fl = FrameLoop(None, mapper, replay=True)
         cloud = cloud_of(g[name + "_cloud_mm"])
         fl.n = len(cloud); fl.cloud[:fl.n] = cloud
         lp = g[name + "_local_pose"]; gp = g[name + "_gpose"]
@@ -129,7 +129,7 @@ def check_frames(golden_dir, loc, mapper, filter_backend=None, frames=None):
     g = load(golden_dir, "frames.npz")
     F = int(g["frames"]) if frames is None else frames
     per_step, P = int(g["per_step"]), int(g["P"])
-    fl = FrameLoop(loc, mapper)
+    fl = FrameLoop(loc, mapper, replay=True)
     st = ParticleMapStep(filter_backend, P) if filter_backend is not None else None
     if st is not None:
         st.set_state(np.full(P, 7.5), np.full(P, 7.5), np.full(P, 1.5), np.zeros(P), np.full(P, 1.0 / P))

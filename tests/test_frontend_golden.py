@@ -77,3 +77,22 @@ def test_callback_and_particle_loop_matches_reference(golden_dir):
     """48 frames of callback() with particle_map() every 8 frames, past a recentring of the
     localisation grid: the reference's own run in the build container."""
     G.check_frames(golden_dir, OracleLocHandle(), OracleMapper(), OracleHandle(50))
+
+
+def test_frame_runs_on_seeds_nobody_screened(golden_dir):
+    """FrameLoop.frame() with arbitrary seeds: the default index draws stay inside the cloud
+    ([0, n-1], like driver/step_loop.cpp's own seeds), so no frame trips over the row behind it; the inclusive
+    draw of S3P:317, 666 is behind replay=True, which the golden fixtures use with their screened seeds. Some seed
+    of this range does draw n inclusively (2400 draws from about 19 000 rows: one frame in nine)."""
+    from slam_amd.frontend import FrameLoop
+    from slam_amd import capi
+    g = G.load(golden_dir, "frames.npz")
+    dims = (200, 200, 80)
+    loc = OracleLocHandle(dims); mapper = OracleMapper(dims)
+    fl = FrameLoop(loc, mapper)
+    image = G.full_image(g["pooled"][0])
+    hit_inclusive = 0
+    for seed in range(1000, 1024):
+        fl.frame(image, g["gyr"][0], seed, seed + 7)           # raises if a ray index left the cloud
+        hit_inclusive += int(np.any(capi.draw_indices(seed + 7, 2400, fl.n) >= fl.n))
+    assert hit_inclusive > 0

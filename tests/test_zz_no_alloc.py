@@ -1,10 +1,12 @@
 """GPU test (-m gpu) of pf_scan_vote_static, the one entry point that allocates nothing (its kernels'
-scratch is a file-scope device array): its output against pf_scan_vote's on the same inputs, bit for
-bit, on two calls in a row, the second with a smaller input; and the size limits."""
+scratch is a file-scope device array): its output against pf_scan_vote's AND the oracle's (pfo_scan_vote) on
+the same inputs, bit for bit, on two calls in a row, the second with a smaller input; that a warmed-up
+call leaves the device's free memory and the caller's current device as they were; and the size limits."""
 import numpy as np
 import pytest
 
 from slam_amd import capi
+from oracle import binding as O
 import golden_util as G
 
 pytestmark = pytest.mark.gpu
@@ -25,6 +27,8 @@ def test_static_scan_vote_equals_scan_vote(golden_dir):
         outs = []
         stream = torch.cuda.Stream(device=dev)
         keep = []
+        capi.scan_vote_static_warmup(0)            # resolves the scratch array's address: from here on nothing is looked up
+        free_before = None
         for name, n, lat in calls:
             grid = np.zeros(G.NL, np.uint8); grid[g[name + "_grid_idx"]] = 1
             cloud = G.cloud_of(g[name + "_cloud_mm"])[:n]
@@ -35,8 +39,14 @@ def test_static_scan_vote_equals_scan_vote(golden_dir):
             t_sums = torch.full((lat["n_yaw"] * lat["n_t"] ** 3,), -7, dtype=torch.int32, device=dev)
             torch.cuda.synchronize()
             keep.append((t_grid, t_pts, t_sums))
+            if free_before is None:
+                free_before = torch.cuda.mem_get_info(dev)[0]
             capi.scan_vote_static(0, stream.cuda_stream, t_grid.data_ptr(), dims, 0.05, t_pts.data_ptr(), len(cloud),
                                   pos, zyx, t_sums.data_ptr(), **lat)
+            if len(outs) == 0:
+                # nothing was allocated by the call (hipMemGetInfo's free bytes are what they were)
+                assert torch.cuda.mem_get_info(dev)[0] == free_before
+            assert torch.cuda.current_device() == 0
             outs.append((name, grid, cloud, pos, zyx, lat, t_sums))
         stream.synchronize()
         for name, grid, cloud, pos, zyx, lat, t_sums in outs:
@@ -45,6 +55,10 @@ def test_static_scan_vote_equals_scan_vote(golden_dir):
             got = t_sums.cpu().numpy()
             assert np.array_equal(got, want), name
             assert want.max() > 0
+            # ... and the oracle's restatement of S3P:328-376 on the same case
+            ref, ref_best = O.scan_vote(grid.reshape(dims), 0.05, cloud, pos, zyx, **lat)
+            assert np.array_equal(got, ref), name
+            assert best == ref_best, name
     finally:
         h.close()
 

@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--beams", type=int, default=4096)
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frame-leg", action="store_true",
+                    help="skip the per-frame path (depth -> cloud -> vote -> ring -> local map) timed after the step")
+    ap.add_argument("--frame-only", action="store_true", help="run only the per-frame leg and print its block (profiling aid)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-update", action="store_true", help="leave K5 out of the step")
     ap.add_argument("--time-all-kernels", action="store_true",
@@ -327,6 +330,107 @@ def fuse_kernels(device):
     return out
 
 
+def frame_leg(reps=3):
+    """The per-frame path beside the particle step (callback(), S3P:168-205): depth image -> cloud -> ring painting
+    -> scan vote -> keyframe ring update -> local-map hits and ray march, on the 48 recorded frames of the
+    reference's own run (tests/golden/frames.npz), through the same C ABI calls the parity tests use
+    (slam_amd.frontend.FrameLoop). Outside the timed region of the step. Every stage hands its result to the host,
+    as the reference's callback does between its calls, so `ms_per_frame` is host-inclusive; `kernel_us` holds the
+    device time of the two stages the library times with events (vote, local-map update). Beside it the same call
+    sequence of the reference itself (oracle/_ref: ref_depth_to_cloud .. ref_build_local_map, g++ -O2 build of
+    its own text) on this host, one thread. Algorithmic bytes per stage, SURVEY 8d style: depth 2 B per pixel in
+    + 24 B per point out; vote 1 B per look-up (hypotheses x points) + 24 B per rotated point; ring 28 B per
+    scan point indexed + 5 B per painted index; local map 24 B per point + 2 B per visited voxel."""
+    import ctypes as C
+    from slam_amd import capi
+    from slam_amd.frontend import FrameLoop
+    fx = os.path.join(ROOT, "tests", "golden", "frames.npz")
+    if not os.path.exists(fx):
+        return None
+    g = np.load(fx)
+    F = int(g["frames"])
+    images = [np.repeat(np.repeat(g["pooled"][f], 4, 0), 4, 1).astype("<u2").tobytes() for f in range(F)]
+    out = {"frames": F, "source": "tests/golden/frames.npz (the reference's own 48-frame run: 640x480 depth, ~19 000 points, "
+                                  "500-point x 625-hypothesis vote, 2400 rays)"}
+    names = ("depth", "ring_paint+vote", "ring_update", "local_map")
+    best = None
+    for rep in range(reps):
+        loc = capi.Handle(capi.default_config(n_particles=1, map_mode=capi.PF_MAP_SHARED, grid_x=200, grid_y=200,
+                                              grid_z=80, local_x=0, local_y=0, local_z=0, max_beams=64))
+        mapper = capi.Handle(capi.default_config(n_particles=1, max_beams=1 << 18))
+        try:
+            loc.fill_maps(0); loc.ring_init()
+            loc.profile(True, [capi.PF_K_VOTE]); mapper.profile(True, [capi.PF_K_UPDATE])
+            fl = FrameLoop(loc, mapper, replay=True)
+            stage = np.zeros(4); bytes_ = np.zeros(4)
+            t_all = time.perf_counter()
+            for f in range(F):
+                t0 = time.perf_counter()
+                fl.depth(images[f])
+                t1 = time.perf_counter()
+                fl.set_gyr(g["gyr"][f])
+                fl.scan_localization(int(g["seed_vote"][f]))
+                t2 = time.perf_counter()
+                fl.map_update()
+                t3 = time.perf_counter()
+                rays = fl.build_local_map(int(g["seed_rays"][f]))
+                t4 = time.perf_counter()
+                stage += (t1 - t0, t2 - t1, t3 - t2, t4 - t3)
+                if rep == 0:
+                    n = fl.n
+                    # visited voxels of the ray march (S3P:676, 685: round(20 |r|) - 1 steps per ray) + the hits within 3 m
+                    d = fl.cloud[:n] * 1.0
+                    rng_ = np.sqrt((d ** 2).sum(1))           # sensor-frame range = range in the local frame
+                    steps = np.maximum(np.round(rng_[rays] * 20.0) - 1, 0).sum()
+                    counts = loc.ring_state()[0]
+                    bytes_ += (2.0 * 640 * 480 + 24.0 * n, 625.0 * 500 + 24.0 * 5 * 500, 28.0 * n + 5.0 * float(np.sum(counts)),
+                               24.0 * n + 2.0 * (float(np.count_nonzero(rng_ <= 3.0)) + float(steps)))
+            mapper.synchronize(); loc.synchronize()
+            wall = time.perf_counter() - t_all
+            kv, nv = loc.kernel_time(capi.PF_K_VOTE); ku, nu = mapper.kernel_time(capi.PF_K_UPDATE)
+            cur = {"ms_per_frame": wall / F * 1e3, "stages_us": {k: float(v) / F * 1e6 for k, v in zip(names, stage)},
+                   "kernel_us": {"vote": kv / max(nv, 1) * 1e3, "local_map": ku / max(nu, 1) * 1e3}}
+            if rep == 0:
+                out["algorithmic_bytes_per_frame"] = {k: float(v) / F for k, v in zip(names, bytes_)}
+            if best is None or cur["ms_per_frame"] < best["ms_per_frame"]:
+                best = cur
+        finally:
+            loc.close(); mapper.close()
+    out.update(best)
+    b = out["algorithmic_bytes_per_frame"]
+    out["roofline"] = {"vote": {"bytes": b["ring_paint+vote"], "launch_us": out["kernel_us"]["vote"],
+                                "frac": b["ring_paint+vote"] / (out["kernel_us"]["vote"] * 1e-6) / 8e12 if out["kernel_us"]["vote"] > 0 else None},
+                       "local_map": {"bytes": b["local_map"], "launch_us": out["kernel_us"]["local_map"],
+                                     "frac": b["local_map"] / (out["kernel_us"]["local_map"] * 1e-6) / 8e12 if out["kernel_us"]["local_map"] > 0 else None}}
+    out["note"] = ("every stage is launch- and copy-bound at the reference's sizes: the kernels take a few us of a call that "
+                   "uploads its input and reads its result back; a device-resident hand-off between the stages would "
+                   "save about the difference between stages_us and kernel_us")
+    # the reference's own callback sequence on this host
+    so = os.path.join(ROOT, "oracle", "_ref", "libs3p_ref.so")
+    if os.path.exists(so):
+        r = C.CDLL(so)
+        r.ref_set_gyr.argtypes = [C.c_double] * 3
+        el = 0.0
+        for rep in range(reps):
+            r.ref_slam_reset()
+            t_rep = 0.0
+            for f in range(F):
+                raw = np.frombuffer(images[f], np.uint8)
+                t0 = time.perf_counter()
+                r.ref_depth_to_cloud(raw.ctypes.data_as(C.c_void_p), len(raw))                 # S3P:173-175
+                r.ref_set_gyr(*[float(v) for v in g["gyr"][f]])
+                r.ref_set_seed(int(g["seed_vote"][f]))
+                r.ref_scan_localization()                                                      # S3P:187
+                r.ref_scan_localization_map_update()                                           # S3P:189
+                r.ref_set_seed(int(g["seed_rays"][f]))
+                r.ref_build_local_map()                                                        # S3P:191
+                t_rep += time.perf_counter() - t0
+            el = t_rep if rep == 0 else min(el, t_rep)
+        out["cpu_reference"] = {"ms_per_frame": el / F * 1e3, "kind": "reference", "cores": 1,
+                                "what": "callback() body of the reference's own text (oracle/_ref), same 48 frames and seeds"}
+    return out
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` launched plainly: one child process per GPU, started before this
     process has touched the GPU, the same rank environment torch.distributed.run would set. Rank 0's
@@ -359,6 +463,9 @@ def update_traffic(sc, pos_list, res=0.05, max_range=3.0):
 
 def main():
     a = parse()
+    if a.frame_only:
+        print(json.dumps({"frame": frame_leg()}), flush=True)
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a)
     import torch
@@ -639,6 +746,11 @@ def main():
             if own:
                 out["cpu_baseline"]["reference_own_case"] = own
             out["cpu_baseline"]["host"] = host_cpu()
+        if not a.no_frame_leg and a.gpus == 1 and not a.force_sharded:
+            try:
+                out["frame"] = frame_leg()
+            except Exception as e:                         # (the step's line is the contract; this block is extra)
+                out["frame"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     h.close()
     if sharded:

@@ -99,6 +99,35 @@ __device__ inline void d5_hits(int i, const PfUpdateWork& uw) {
     if (cell_touch(grid, f, up.hit_inc, up.hit_clamp, true, up.is_signed != 0))
         shadow_touch(up, f, up.hit_inc, up.hit_clamp, true);
 }
+// The same for a whole wave (every lane calls): neighbouring points of a depth image mostly fall into the same
+// voxel, so a run of consecutive lanes with one flat index is ONE touch of (run length) * increment by its first
+// lane (k touches of v -> min(v + inc, clamp) are one touch of k * inc), a third of the compare-and-swaps on the
+// reference's 19 200-point clouds.
+__device__ inline void d5_hits_wave(int i, const PfUpdateWork& uw) {
+    const PfUpdateParams& up = uw.up;
+    long long f = -1;
+    if (i < uw.M) {
+        const double* __restrict__ points = uw.points;
+        const double px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
+        const double wx = (up.rot[0] * px + up.rot[1] * py + up.rot[2] * pz) + up.pos[0];   // S3P:547-549, 555-557
+        const double wy = (up.rot[3] * px + up.rot[4] * py + up.rot[5] * pz) + up.pos[1];
+        const double wz = (up.rot[6] * px + up.rot[7] * py + up.rot[8] * pz) + up.pos[2];
+        uw.wpts[3 * (size_t)i] = wx; uw.wpts[3 * (size_t)i + 1] = wy; uw.wpts[3 * (size_t)i + 2] = wz;
+        const double dx = wx - up.pos[0], dy = wy - up.pos[1], dz = wz - up.pos[2];
+        const double nrm = sqrt(dx * dx + dy * dy + dz * dz);        // S3P:615-617
+        if (!(nrm > up.max_range)) f = flat_of(wx * up.conv, wy * up.conv, wz * up.conv, up);   // S3P:637 (NaN falls through)
+    }
+    const int lane = threadIdx.x & 63;
+    const int flo = (int)f;                                          // (f < 2^31: the grids' cell counts are below it)
+    const int prev = __shfl_up(flo, 1, 64);
+    const bool head = f >= 0 && (lane == 0 || prev != flo);
+    const unsigned long long heads = __ballot(head || f < 0);        // a lane without a cell ends a run too
+    if (!head) return;
+    const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+    const int run = above ? __ffsll((long long)above) : 64 - lane;
+    if (cell_touch(uw.grid, f, run * up.hit_inc, up.hit_clamp, true, up.is_signed != 0))
+        shadow_touch(up, f, run * up.hit_inc, up.hit_clamp, true);
+}
 
 // S3P:664-704 for ray r: PF_RAY_LANES lanes per ray (two rays per wave: a ray of the 3 m range has
 // at most 60 steps, and half as many waves fit the chip in one residency instead of two and a
@@ -119,7 +148,7 @@ __device__ inline void d5_rays(int r, int lane, const PfUpdateWork& uw) {
     if (!(rr < 2147483648.0)) return;                            // also drops NaN
     const int n_it = (int)rr;
     const double sx = dx / nc, sy = dy / nc, sz = dz / nc;       // S3P:681-683
-    for (int j = 1 + lane; j < n_it; j += PF_RAY_LANES) {
+    for (int j = 1 + uw.near_steps + lane; j < n_it; j += PF_RAY_LANES) {
         const double jd = (double)j;
         const long long f = flat_of((up.pos[0] + sx * jd) * up.conv, (up.pos[1] + sy * jd) * up.conv,
                                     (up.pos[2] + sz * jd) * up.conv, up);   // S3P:687-690
@@ -130,3 +159,57 @@ __device__ inline void d5_rays(int r, int lane, const PfUpdateWork& uw) {
     }
 }
 
+
+// The first uw.near_steps steps of the rays r0, r0 + stride, ... (S3P:685-700), counted per cell in an LDS table
+// (16-bit counters, two to a word: a cell sees at most R < 65536 touches) over the box around the sensor's cell,
+// then applied once per cell. A step whose cell is off an axis (the flat index aliases, S3P:691) or outside the
+// box is touched directly. Call with every thread of the workgroup; tbl: PF_NEAR_TBL_WORDS words of LDS.
+#define PF_NEAR_TBL_WORDS ((PF_NEAR_W * PF_NEAR_W * PF_NEAR_W + 1) / 2)
+__device__ inline void d5_rays_near(int r0, int stride, const PfUpdateWork& uw, unsigned* tbl) {
+    const PfUpdateParams& up = uw.up;
+    for (int k = threadIdx.x; k < PF_NEAR_TBL_WORDS; k += blockDim.x) tbl[k] = 0u;
+    __syncthreads();
+    const long long gyz = (long long)up.gy * up.gz;
+    const int gx = (int)(up.elements / gyz);
+    // the box's centre: the sensor's own cell (any cell would do: a step outside the box goes the direct way)
+    const double cxd = round(up.pos[0] * up.conv), cyd = round(up.pos[1] * up.conv), czd = round(up.pos[2] * up.conv);
+    const bool centre_ok = fabs(cxd) < 1e9 && fabs(cyd) < 1e9 && fabs(czd) < 1e9;
+    const int cx = centre_ok ? (int)cxd : 0, cy = centre_ok ? (int)cyd : 0, cz = centre_ok ? (int)czd : 0;
+    for (int r = r0 + (int)threadIdx.x * stride; r < uw.R; r += (int)blockDim.x * stride) {
+        const double* e = uw.wpts + 3 * (size_t)uw.ray_idx[r];
+        const double dx = e[0] - up.pos[0], dy = e[1] - up.pos[1], dz = e[2] - up.pos[2];
+        const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+        const double nc = nrm * up.conv;
+        const double rr = round(nc);                                 // S3P:676
+        if (!(rr < 2147483648.0)) continue;
+        const int n_it = (int)rr;
+        const double sx = dx / nc, sy = dy / nc, sz = dz / nc;       // S3P:681-683
+        const int j1 = min(n_it, 1 + uw.near_steps);
+        for (int j = 1; j < j1; ++j) {
+            const double jd = (double)j;
+            const double X = round((up.pos[0] + sx * jd) * up.conv), Y = round((up.pos[1] + sy * jd) * up.conv),
+                         Z = round((up.pos[2] + sz * jd) * up.conv);   // S3P:687-690
+            if (!(fabs(X) < 2147483648.0 && fabs(Y) < 2147483648.0 && fabs(Z) < 2147483648.0)) continue;
+            const long long f = (long long)X * up.gy * up.gz + (long long)Y * up.gz + (long long)Z;
+            if (f < 0 || f >= up.elements) continue;                 // S3P:691
+            const int xi = (int)X, yi = (int)Y, zi = (int)Z;
+            const unsigned bx = (unsigned)(xi - cx + PF_NEAR_R), by = (unsigned)(yi - cy + PF_NEAR_R), bz = (unsigned)(zi - cz + PF_NEAR_R);
+            if (centre_ok && bx < PF_NEAR_W && by < PF_NEAR_W && bz < PF_NEAR_W && (unsigned)xi < (unsigned)gx &&
+                (unsigned)yi < (unsigned)up.gy && (unsigned)zi < (unsigned)up.gz) {
+                const unsigned slot = (bx * PF_NEAR_W + by) * PF_NEAR_W + bz;
+                atomicAdd(&tbl[slot >> 1], 1u << (16u * (slot & 1u)));
+            } else if (cell_touch(uw.grid, f, up.miss_inc, up.miss_clamp, false, up.is_signed != 0)) {
+                shadow_touch(up, f, up.miss_inc, up.miss_clamp, false);
+            }
+        }
+    }
+    __syncthreads();
+    for (int slot = threadIdx.x; slot < PF_NEAR_W * PF_NEAR_W * PF_NEAR_W; slot += blockDim.x) {
+        const unsigned k = (tbl[slot >> 1] >> (16u * ((unsigned)slot & 1u))) & 0xffffu;
+        if (!k) continue;
+        const int bz = slot % PF_NEAR_W, by = (slot / PF_NEAR_W) % PF_NEAR_W, bx = slot / (PF_NEAR_W * PF_NEAR_W);
+        const long long f = (long long)(bx + cx - PF_NEAR_R) * up.gy * up.gz + (long long)(by + cy - PF_NEAR_R) * up.gz + (bz + cz - PF_NEAR_R);
+        if (cell_touch(uw.grid, f, (int)k * up.miss_inc, up.miss_clamp, false, up.is_signed != 0))
+            shadow_touch(up, f, (int)k * up.miss_inc, up.miss_clamp, false);
+    }
+}

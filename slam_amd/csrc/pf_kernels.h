@@ -297,7 +297,18 @@ struct PfUpdateWork {
     const int32_t* ray_idx; // [R]
     int M, R;
     PfUpdateParams up;
+    int near_steps;         // > 0: the rays' first near_steps steps are counted per cell in LDS by d5_rays_near's workgroups
+                            // and d5_rays starts behind them; 0: d5_rays marches every step
 };
+// Every ray starts at the sensor: its first steps land in the same few hundred cells as every other ray's, and a
+// compare-and-swap per touch on those words serialises (2400 rays on the reference's empty local map: 217 us of
+// ray march, profiles/r3_frame_*). The first PF_NEAR_STEPS steps are therefore counted per cell in an LDS table
+// over the box of PF_NEAR_R cells around the sensor's cell, and each cell gets ONE touch of count * increment
+// (k touches of v -> max(v + inc, clamp) are one touch of k * inc: same result, any order).
+#define PF_NEAR_STEPS 14
+#define PF_NEAR_R (PF_NEAR_STEPS + 2)
+#define PF_NEAR_W (2 * PF_NEAR_R + 1)
+#define PF_NEAR_WGS 8       // workgroups that share the rays' near steps (each applies its own counts)
 bool pfk_weights_carries(int Pg, bool exact, const int32_t* bmin);
 // block minima of sum_match for scores from outside (pf_weights with gathered scores): bmin[pfk_block_minima_count(Pg)]
 int pfk_block_minima_count(int Pg);

@@ -973,10 +973,17 @@ hipError_t pfk_voxel_indices(hipStream_t st, const double* pose, int P, int i,
 // the ray march starts, as in S3P:632-661 then S3P:668-704.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_update_hits(PfUpdateWork uw) {
-    d5_hits(blockIdx.x * 256 + threadIdx.x, uw);
+    d5_hits_wave(blockIdx.x * 256 + threadIdx.x, uw);
 }
 __global__ __launch_bounds__(256) void k_update_rays(PfUpdateWork uw) {
     d5_rays(blockIdx.x * PF_RAYS_PER_WG + threadIdx.x / PF_RAY_LANES, threadIdx.x % PF_RAY_LANES, uw);
+}
+// The same with the rays' near steps counted in LDS: workgroups 0 .. PF_NEAR_WGS-1 take them (a ray in eight each),
+// the others march the steps behind (uw.near_steps > 0).
+__global__ __launch_bounds__(256) void k_update_rays_near(PfUpdateWork uw) {
+    __shared__ unsigned tbl[PF_NEAR_TBL_WORDS];
+    if (blockIdx.x < PF_NEAR_WGS) { d5_rays_near((int)blockIdx.x, PF_NEAR_WGS, uw, tbl); return; }
+    d5_rays((blockIdx.x - PF_NEAR_WGS) * PF_RAYS_PER_WG + threadIdx.x / PF_RAY_LANES, threadIdx.x % PF_RAY_LANES, uw);
 }
 
 __global__ __launch_bounds__(256) void k_fill_u8(uint4* dst, unsigned long long n16, uint4 v) {
@@ -992,6 +999,14 @@ hipError_t pfk_update_hits(hipStream_t st, const PfUpdateWork& uw) {
 }
 hipError_t pfk_update_rays(hipStream_t st, const PfUpdateWork& uw) {
     if (uw.R == 0) return hipSuccess;
+    // SLAM_PF_NEAR=0: every step by compare-and-swap (comparison); few rays: not worth the table
+    static const bool near_wanted = !(getenv("SLAM_PF_NEAR") && atoi(getenv("SLAM_PF_NEAR")) == 0);
+    if (near_wanted && uw.R >= 256 && uw.R < 65536) {
+        PfUpdateWork w = uw;
+        w.near_steps = PF_NEAR_STEPS;
+        hipLaunchKernelGGL(k_update_rays_near, dim3(PF_NEAR_WGS + (uw.R + PF_RAYS_PER_WG - 1) / PF_RAYS_PER_WG), dim3(256), 0, st, w);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_update_rays, dim3((uw.R + PF_RAYS_PER_WG - 1) / PF_RAYS_PER_WG), dim3(256), 0, st, uw);
     return hipGetLastError();
 }
@@ -1165,30 +1180,48 @@ __global__ __launch_bounds__(256) void k_depth_pool(const uint8_t* __restrict__ 
     const double vertical = -1 * ((i + 1) - (res_v / 2)) / focal;          // S3P:161
     dpix[p] = make_int4((int)(depth_y * horizontal), depth_y, (int)(depth_y * vertical), 0);
 }
+// Rounds of up to 32 tiles of 1024 pixels: every thread first reads the depth of its pixel in each tile of the
+// round (independent loads, all in flight: the one-tile-at-a-time form took 27 us for the reference's 19 200
+// pixels, one dependent round trip and three barriers per tile), the wave counts go to LDS, wave 0 scans them
+// in tile-major order, then every kept pixel is written at its rank.
 __global__ __launch_bounds__(1024) void k_depth_compact(const int4* __restrict__ dpix, int npix,
                                                         double* __restrict__ cloud, int32_t* count_out) {
-    __shared__ int wtot[16];
+    __shared__ int wcnt[32 * 16];        // [tile][wave] of the round, then their exclusive prefix
     __shared__ int base_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) base_s = 0;
-    __syncthreads();
-    for (int t0 = 0; t0 < npix; t0 += 1024) {
-        const int p = t0 + tid;
-        int4 d = make_int4(0, 0, 0, 0);
-        if (p < npix) d = dpix[p];
-        const bool keep = d.y != 0;                                         // S3P:602
-        const unsigned long long m = __ballot(keep);
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wtot[wv] = __popcll(m);
-        __syncthreads();
-        int off = base_s;
-        for (int k = 0; k < wv; ++k) off += wtot[k];
-        if (keep) {
-            double* o = cloud + 3 * (size_t)(off + rank);
-            o[0] = d.x / 1000.0; o[1] = d.y / 1000.0; o[2] = d.z / 1000.0;   // S3P:603-605
+    for (int r0 = 0; r0 < npix; r0 += 32 * 1024) {
+        const int nt = min(32, (npix - r0 + 1023) / 1024);
+        unsigned keepbits = 0u;
+        for (int t = 0; t < nt; ++t) {
+            const int p = r0 + t * 1024 + tid;
+            const bool keep = p < npix && dpix[p].y != 0;                    // S3P:602
+            keepbits |= keep ? 1u << t : 0u;
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) wcnt[t * 16 + wv] = __popcll(m);
         }
         __syncthreads();
-        if (tid == 0) { int sum = 0; for (int k = 0; k < 16; ++k) sum += wtot[k]; base_s += sum; }
+        if (wv == 0) {                                                       // 512 counts: eight per lane + a wave scan
+            int v[8], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = lane * 8 + k; v[k] = i < nt * 16 ? wcnt[i] : 0; sum += v[k]; }
+            int inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o, 64); if (lane >= o) inc += x; }
+            int run = base_s + inc - sum;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = lane * 8 + k; if (i < nt * 16) wcnt[i] = run; run += v[k]; }
+            if (lane == 63) base_s = run;                                    // (read above by every lane of this wave only)
+        }
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            const bool keep = (keepbits >> t) & 1u;
+            const unsigned long long m = __ballot(keep);
+            if (!keep) continue;
+            const int4 d = dpix[r0 + t * 1024 + tid];
+            double* o = cloud + 3 * (size_t)(wcnt[t * 16 + wv] + __popcll(m & ((1ull << lane) - 1ull)));
+            o[0] = d.x / 1000.0; o[1] = d.y / 1000.0; o[2] = d.z / 1000.0;   // S3P:603-605
+        }
         __syncthreads();
     }
     if (tid == 0) *count_out = base_s;

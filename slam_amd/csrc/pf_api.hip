@@ -243,6 +243,8 @@ struct pf_handle {
     std::vector<int32_t> h_slots, mg_src, mg_speer, mg_dst, mg_rpeer;   // map migration (per-particle maps, sharded)
     std::vector<int64_t> mg_sseq, mg_rseq;
     bool group_gathers = true;
+    int virtual_shards = 0;            // SLAM_PF_VIRTUAL_SHARDS (test switch, world 1 only): the shard's slabs move between
+                                       // this many equal blocks of slots through the send/receive groups, peer = this rank
     double* poses_all = nullptr;       // [world][9][P]
     // profiling
     bool profile = false;
@@ -1447,7 +1449,7 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
     if (!u && !h->have_u) return fail(h, PF_ERR_ARG, "pf_resample: no thresholds resident");
     if (h->Pg != h->P && !poses_global_dev && !h->comm)
         return fail(h, PF_ERR_ARG, "pf_resample: sharded handle needs the gathered pose blocks (or pf_comm_init)");
-    const bool migrate = h->slab && h->Pg != h->P;
+    const bool migrate = h->slab && (h->Pg != h->P || h->virtual_shards > 1);
     if (migrate && !(h->comm && rccl().Send && rccl().Recv && rccl().GroupStart && rccl().GroupEnd))
         return fail(h, PF_ERR_ARG, "pf_resample: per-particle maps on a sharded handle move between ranks "
                                    "inside the library: pf_comm_init first");
@@ -1505,7 +1507,8 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
                                 h->slab, (unsigned long long)h->elements, h->draw, h->first, h->dup_anc,
                                 h->free_slot, h->slot_anc, h->best, h->counters, h->rs, h->d_result + h->result_slot_u64 * slot,
                                 count_keys ? h->order_hist[0] : nullptr, h->order_keys, op,
-                                h->weighted && !h->exact));   // the FAST-order weight kernels left the block-end table behind the CDF
+                                h->weighted && !h->exact,     // the FAST-order weight kernels left the block-end table behind the CDF
+                                h->virtual_shards > 1 ? h->P / h->virtual_shards : 0));
         h->hist_counted = count_keys;
         h->pose_src = nullptr;                        // every row is in h->pose now
     }
@@ -1518,34 +1521,40 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
         // ones, so no transfer reads what another writes.
         const size_t Pg = (size_t)h->Pg;
         h->h_slots.resize(Pg);
-        for (auto* v : {&h->mg_src, &h->mg_speer, &h->mg_dst, &h->mg_rpeer}) v->resize(Pg);
-        h->mg_sseq.resize(Pg); h->mg_rseq.resize(Pg);
         HIP_TRY(h, hipMemcpyAsync(h->h_slots.data(), h->slot_anc, sizeof(int32_t) * Pg, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        int64_t ns = 0, nr = 0;
-        pfh_migration_plan(h->h_slots.data(), h->Pg, h->P, h->comm_rank, h->mg_src.data(), h->mg_speer.data(),
-                           h->mg_sseq.data(), &ns, h->mg_dst.data(), h->mg_rpeer.data(), h->mg_rseq.data(), &nr,
-                           (int64_t)Pg);
-        // one RCCL group per PF_MIGRATE_GROUP transfer numbers: the same cut on every rank
+        // The transfers this process takes part in, in transfer-number order: a rank's own sends and receives, or
+        // (SLAM_PF_VIRTUAL_SHARDS, one rank) those of every virtual shard, whose peer is this rank itself; a
+        // transfer between two virtual shards then has its send and its receive in the same group.
+        struct Xfer { int64_t seq; int32_t slot, peer; bool send; };
+        std::vector<Xfer> xf;
+        const int V = h->virtual_shards > 1 ? h->virtual_shards : 1;
+        const int Pv = h->P / V;
+        for (auto* v : {&h->mg_src, &h->mg_speer, &h->mg_dst, &h->mg_rpeer}) v->resize(Pg);
+        h->mg_sseq.resize(Pg); h->mg_rseq.resize(Pg);
+        for (int v = 0; v < V; ++v) {
+            int64_t ns = 0, nr = 0;
+            pfh_migration_plan(h->h_slots.data(), h->Pg, Pv, V > 1 ? v : h->comm_rank, h->mg_src.data(), h->mg_speer.data(),
+                               h->mg_sseq.data(), &ns, h->mg_dst.data(), h->mg_rpeer.data(), h->mg_rseq.data(), &nr,
+                               (int64_t)Pg);
+            const int32_t base = V > 1 ? v * Pv : 0;                 // a virtual shard's slots inside this rank's maps
+            for (int64_t k = 0; k < ns; ++k)
+                xf.push_back(Xfer{h->mg_sseq[(size_t)k], base + h->mg_src[(size_t)k], V > 1 ? h->comm_rank : h->mg_speer[(size_t)k], true});
+            for (int64_t k = 0; k < nr; ++k)
+                xf.push_back(Xfer{h->mg_rseq[(size_t)k], base + h->mg_dst[(size_t)k], V > 1 ? h->comm_rank : h->mg_rpeer[(size_t)k], false});
+        }
+        // (a rank's two lists ascend in the transfer number; merged: by number, a number's send before its receive)
+        std::stable_sort(xf.begin(), xf.end(), [](const Xfer& a, const Xfer& b) { return a.seq != b.seq ? a.seq < b.seq : a.send && !b.send; });
+        // one RCCL group per kGroup transfer numbers: the same cut on every rank
         const int64_t kGroup = 512;
-        int64_t is = 0, ir = 0;
-        while (is < ns || ir < nr) {
-            const int64_t next = is < ns && (ir >= nr || h->mg_sseq[(size_t)is] < h->mg_rseq[(size_t)ir])
-                                     ? h->mg_sseq[(size_t)is] : h->mg_rseq[(size_t)ir];
-            const int64_t end = (next / kGroup + 1) * kGroup;
+        size_t ix = 0;
+        while (ix < xf.size()) {
+            const int64_t end = (xf[ix].seq / kGroup + 1) * kGroup;
             ncclResult_t r = rccl().GroupStart();
-            while (r == ncclSuccess && (is < ns || ir < nr)) {
-                const bool s_ok = is < ns && h->mg_sseq[(size_t)is] < end, r_ok = ir < nr && h->mg_rseq[(size_t)ir] < end;
-                if (!s_ok && !r_ok) break;
-                if (s_ok && (!r_ok || h->mg_sseq[(size_t)is] < h->mg_rseq[(size_t)ir])) {
-                    r = rccl().Send(h->maps + h->slab * (unsigned long long)h->mg_src[(size_t)is], (size_t)h->elements,
-                                    ncclUint8, h->mg_speer[(size_t)is], h->comm, h->stream);
-                    ++is;
-                } else {
-                    r = rccl().Recv(h->maps + h->slab * (unsigned long long)h->mg_dst[(size_t)ir], (size_t)h->elements,
-                                    ncclUint8, h->mg_rpeer[(size_t)ir], h->comm, h->stream);
-                    ++ir;
-                }
+            for (; r == ncclSuccess && ix < xf.size() && xf[ix].seq < end; ++ix) {
+                uint8_t* slab = h->maps + h->slab * (unsigned long long)xf[ix].slot;
+                r = xf[ix].send ? rccl().Send(slab, (size_t)h->elements, ncclUint8, xf[ix].peer, h->comm, h->stream)
+                                : rccl().Recv(slab, (size_t)h->elements, ncclUint8, xf[ix].peer, h->comm, h->stream);
             }
             const ncclResult_t e = rccl().GroupEnd();
             if (r == ncclSuccess) r = e;
@@ -2030,6 +2039,11 @@ int pf_comm_init(pf_handle* h, const void* id, int32_t rank, int32_t world) {
     }
     h->comm_world = world;
     h->comm_rank = rank;
+    // test switch: on one rank, per-particle maps move between virtual shards through the same send/receive groups
+    if (const char* e = getenv("SLAM_PF_VIRTUAL_SHARDS")) {
+        const int v = atoi(e);
+        if (world == 1 && h->slab && v > 1 && h->P % v == 0) h->virtual_shards = v;
+    }
     HIP_TRY(h, materialize_pose(h));
     HIP_TRY(h, dalloc(&h->scores_all, (size_t)h->Pg));
     HIP_TRY(h, dalloc(&h->bmin_all, (size_t)world * (size_t)h->n_bmin));

@@ -257,7 +257,7 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
                         int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
                         unsigned long long* counters, PfResampleScratch sc,
                         unsigned long long* host_out, int32_t* order_hist, int32_t* order_keys,
-                        PfOrderParams op, bool tops_valid = false);
+                        PfOrderParams op, bool tops_valid = false, int map_vshard = 0);
 
 #define PF_RESULT_HEADER 4
 #define PF_RESULT_BLOCKS (1ull << 63)

@@ -1300,11 +1300,14 @@ __global__ __launch_bounds__(NB) void k4_apply_shard(int32_t* slot_anc, const in
 __global__ __launch_bounds__(NB) void k_apply_maps(const int32_t* __restrict__ slot_anc, int P,
                                                    int offset, uint8_t* maps,
                                                    unsigned long long stride,
-                                                   unsigned long long bytes) {
+                                                   unsigned long long bytes, int vshard) {
     const int i = blockIdx.x;
     const int a = slot_anc[offset + i];
     if (a == offset + i) return;
     if (a < offset || a >= offset + P) return;               // another rank's slab: pf_resample receives it
+    // (test switch SLAM_PF_VIRTUAL_SHARDS: the shard is treated as blocks of vshard slots that exchange their
+    // slabs through the library's send/receive groups like ranks do)
+    if (vshard > 0 && (a - offset) / vshard != i / vshard) return;
     const uint4* src = (const uint4*)(maps + stride * (unsigned long long)(a - offset));
     uint4* dst = (uint4*)(maps + stride * (unsigned long long)i);
     const unsigned long long n16 = (bytes + 15) / 16;        // slabs are padded to 256 B
@@ -1393,7 +1396,7 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
                         int32_t* dup_anc, int32_t* free_slot, int32_t* slot_anc, int32_t* best,
                         unsigned long long* counters, PfResampleScratch sc,
                         unsigned long long* host_out, int32_t* order_hist, int32_t* order_keys,
-                        PfOrderParams op, bool tops_valid) {
+                        PfOrderParams op, bool tops_valid, int map_vshard) {
     const int nb = nblocks(Pg);
     // counters[0..2] and first[] were initialised by the weight kernels of this step
     if (!pose_src) pose_src = pose;
@@ -1460,7 +1463,7 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
         if (gy < 1) gy = 1;
         if (gy > 64) gy = 64;
         hipLaunchKernelGGL(k_apply_maps, dim3(P, gy), dim3(NB), 0, st, slot_anc, P, offset, maps,
-                           map_stride, map_bytes);
+                           map_stride, map_bytes, map_vshard);
     }
     if (!host_argmax)
         hipLaunchKernelGGL(k4_argmax, dim3(1), dim3(WG), 0, st, nb, sc.bbest_v, sc.bbest_i, best, counters,

@@ -114,7 +114,8 @@ struct pf_handle {
                                        // holds two PfColG per group: the lz of its beams 0-3 and 4-7)
     struct TileGroupH { float lx, ly; int32_t n; int32_t lz[PF_TILE_GROUP]; };
     std::vector<TileGroupH> h_tg, h_tg_tmp;
-    int tile_ends[PF_TILE_GROUP] = {0};   // ends of the groups with PF_TILE_GROUP, ..., 1 beams in beams_tile
+    int tile_ends[PF_TILE_GROUP] = {0};   // ends of the groups with PF_TILE_GROUP, ..., 1 beams in the sorted list
+    int tile_chunks = 1;               // chunks the list in beams_tile was dealt to (its first tile_chunks records are their table)
     int lz_min = 0, lz_max = 0;        // bounds of lz over the occupied beams
     std::vector<unsigned long long> h_sort_keys;
     // k_measure_box: the same groups ordered by cluster, the clusters ordered by blockIdx.y group
@@ -742,7 +743,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
         CREATE_TRY(dalloc(&h->local, (size_t)round_up((unsigned long long)h->local_elements, 256)));
     {
         const size_t mb = (size_t)c.max_beams;
-        h->beam_blk_bytes = 64 * 9 + sizeof(PfBeam) * mb + sizeof(PfTileG) * (mb + 1) + sizeof(PfColG) * 2 * (mb + 1) + sizeof(PfBeam) * (mb + PF_BEAM_GROUP) +
+        h->beam_blk_bytes = 64 * 9 + sizeof(PfBeam) * mb + sizeof(PfTileG) * (mb + 1 + 1024) + sizeof(PfColG) * 2 * (mb + 1) + sizeof(PfBeam) * (mb + PF_BEAM_GROUP) +
                             sizeof(PfBeamF) * (mb + PF_BEAM_GROUP) + sizeof(PfColG) * (mb + 1) + sizeof(PfCluster) * (mb + 1) +
                             sizeof(int) * 257;
         if (c.map_mode == PF_MAP_PER_PARTICLE)      // worst case, every beam a column of its own: 32 B + two units
@@ -1150,26 +1151,53 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         for (const auto& g : tg) { zmin = std::min(zmin, g.lz[0]); zmax = std::max(zmax, g.lz[g.n - 1]); }
         if (tg.empty()) zmin = zmax = 0;
         h->lz_min = zmin; h->lz_max = zmax;
-        h->h_tcols.resize(tg.size());
-        h->h_cols.resize(2 * tg.size());
-        for (size_t i = 0; i < tg.size(); ++i) {
-            const auto& g = tg[i];
+        h->n_cols = (int)tg.size();
+        int e = 0;
+        for (int n = PF_TILE_GROUP; n >= 1; --n) {
+            while (e < h->n_cols && tg[(size_t)e].n == n) ++e;
+            h->tile_ends[PF_TILE_GROUP - n] = e;
+        }
+        // The chunks (blockIdx.y) of k_measure_tile: >= 12 groups (about 32 beams) each. The groups of a count go
+        // tile_trip(count) to a trip, the trips of the whole list are numbered through and trip j belongs to chunk
+        // j % C, so every chunk gets the same number of trips of every size to within one (a count's last trip may
+        // be short). The list the kernel reads is CHUNK-MAJOR: a chunk's groups lie together, counts descending,
+        // behind a table of C records (64 B each: the ends of its eight counts, then its start), so that a wave
+        // finds its share with one scalar load, walks contiguous memory and divides nothing.
+        int C = h->tune_chunks > 0 ? h->tune_chunks : h->max_chunks;
+        if (C > h->max_chunks) C = h->max_chunks;
+        if (C > (h->n_cols + 11) / 12) C = (h->n_cols + 11) / 12;
+        if (C < 1) C = 1;
+        h->tile_chunks = C;
+        std::vector<pf_handle::TileGroupH>& pg = h->h_tg_tmp;
+        pg.clear(); pg.reserve(tg.size());
+        h->h_tcols.assign((size_t)C + tg.size(), PfTileG{});
+        for (int y = 0; y < C; ++y) {
+            int32_t* row = (int32_t*)&h->h_tcols[(size_t)y];
+            row[PF_TILE_GROUP] = (int32_t)pg.size();
+            long long slot0 = 0;
+            int g0 = 0;
+            for (int ph = 0; ph < PF_TILE_GROUP; ++ph) {
+                const int g1 = h->tile_ends[ph], T = pfk_tile_trip(PF_TILE_GROUP - ph);
+                const long long nslots = (g1 - g0 + T - 1) / T;
+                for (long long sl = ((y - slot0) % C + C) % C; sl < nslots; sl += C)
+                    for (int g = g0 + (int)sl * T; g < std::min(g0 + ((int)sl + 1) * T, g1); ++g) pg.push_back(tg[(size_t)g]);
+                row[ph] = (int32_t)pg.size();
+                slot0 += nslots; g0 = g1;
+            }
+        }
+        h->h_cols.resize(2 * pg.size());
+        for (size_t i = 0; i < pg.size(); ++i) {
+            const auto& g = pg[i];
             PfTileG t{};
             t.lx = g.lx; t.ly = g.ly; t.n = g.n;
             for (int k = 0; k < PF_TILE_GROUP; ++k) t.lza[k] = (uint32_t)(g.lz[k] - zmin) * h->swz.a;   // (mod 2^32: used only when the layer is inside the grid)
-            h->h_tcols[i] = t;
+            h->h_tcols[(size_t)C + i] = t;
             for (int half = 0; half < 2; ++half) {
                 PfColG c{};
                 c.lx = g.lx; c.ly = g.ly; c.n = std::max(0, std::min(4, g.n - 4 * half));
                 for (int k = 0; k < 4; ++k) c.lz[k] = g.lz[4 * half + k];
                 h->h_cols[2 * i + (size_t)half] = c;
             }
-        }
-        h->n_cols = (int)tg.size();
-        int e = 0;
-        for (int n = PF_TILE_GROUP; n >= 1; --n) {
-            while (e < h->n_cols && tg[(size_t)e].n == n) ++e;
-            h->tile_ends[PF_TILE_GROUP - n] = e;
         }
     }
     // everything goes through one pinned, double-buffered block: the call does not wait for the stream
@@ -1321,9 +1349,11 @@ int pf_measure(pf_handle* h, int add_points) {
             if (cch > (h->n_cols + 11) / 12) cch = (h->n_cols + 11) / 12;
             if (cch < 1) cch = 1;
             chunks = cch;
-            if (h->swz.kind == PF_LAYOUT_TILES)
+            if (h->swz.kind == PF_LAYOUT_TILES) {
+                chunks = h->tile_chunks;               // (the list was dealt to this many chunks by pf_set_beams)
                 HIP_TRY(h, pfk_measure_tile(h->stream, h->sorted, h->lanes, h->order, h->shadow, h->maps, h->swz, h->beams_tile, h->beams_col,
-                                            h->tile_ends, h->lz_min, h->lz_max, chunks, grid_params(h), h->lmax_occ, h->partial));
+                                            h->lz_min, h->lz_max, chunks, grid_params(h), h->lmax_occ, h->partial));
+            }
             else
             HIP_TRY(h, pfk_measure_col(h->stream, h->sorted, h->P, h->shadow, h->swz, h->beams_col, h->n_runs, h->col_ends,
                                        chunks, grid_params(h), h->lmax_occ, h->order, h->partial));

@@ -171,16 +171,17 @@ struct __attribute__((aligned(64))) PfTileG {
     int32_t pad1[4];
 };
 // K1 on the tile layout (shared grid only): one coalesced window load per beam and wave, every lane's byte
-// handed over by ds_bpermute (pf_measure_tile.hip). cg: the column groups sorted by their number of beams,
-// group_ends[k] = end of the groups with PF_TILE_GROUP - k beams; cgz: their lz (two PfColG per group); lzmin,
-// lzmax: the bounds of lz over the list.
+// handed over by ds_bpermute (pf_measure_tile.hip). cg: a table of n_chunks records of 64 B (ints: [k] = end of
+// the chunk's groups with PF_TILE_GROUP - k beams, [PF_TILE_GROUP] = its start; indices into the list behind the
+// table), then the column groups chunk by chunk, inside a chunk by their number of beams (descending); cgz: the
+// groups' lz in the same order (two PfColG per group); lzmin, lzmax: the bounds of lz over the list.
 // lin: the same grid in the reference's order (the beams that leave the grid read it through the flat index).
 // lanes = pfk_padded_lanes(P), order/sorted from pfk_order with op.zsplit; partial: int2 [n_chunks][lanes]
 // in lane order.
 hipError_t pfk_measure_tile(hipStream_t st, const double* sorted, int lanes, const int32_t* order,
-                            const uint8_t* shadow, const uint8_t* lin, PfSwz sw, const PfTileG* cg, const PfColG* cgz, const int group_ends[PF_TILE_GROUP],
+                            const uint8_t* shadow, const uint8_t* lin, PfSwz sw, const PfTileG* cg, const PfColG* cgz,
                             int lzmin, int lzmax, int n_chunks, PfGridParams gp, double lmax, int2* partial);
-int pfk_tile_slot();     // column groups per trip of k_measure_tile (the unit its chunks are dealt in)
+int pfk_tile_trip(int n_beams);     // column groups per trip of k_measure_tile for groups of n_beams beams
 // K1 on the gather layout (shared grid only), the beams grouped by column (PfColG): cg[0 .. n_runs) are
 // RUN groups (the occupied cells of one column inside an 8-cell z window: lz[0] = first z, lz[1], lz[2] =
 // a byte of 1 per occupied cell 0-3, 4-7, n = their number), then the plain groups sorted by their number

@@ -34,13 +34,14 @@
 #include <stdlib.h>
 
 #ifndef TILE_EXP
-#define TILE_EXP 0      // development: 1 no window loads, 2 no ds_bpermute, 3 neither (wrong results, timing only)
+#define TILE_EXP 0      // development: 1 no window loads, 2 no ds_bpermute, 3 neither, 4 prologue and epilogue only, 5 no work per beam
+                        // (wrong results, timing only)
 #endif
 #ifndef TILE_T
-#define TILE_T 3        // column groups per trip for groups of up to four beams (their loads are in flight together; 2: 27.6,
-#endif                  // 3: 26.3, 4: 30.0 us at configs[1] with groups of at most four)
-#ifndef TILE_T8
-#define TILE_T8 2       // ... for groups of five to eight beams
+#define TILE_T 2        // column groups per trip for groups of up to four beams (their loads are in flight together). With the
+#endif                  // chunk-major list (3, 2): 23.4 us at configs[1], (3, 1): 22.8, (2, 1): 22.4, (4, 2): 28.6; the kernel sits
+#ifndef TILE_T8         // at its register limits (64 vector, 78 scalar at eight waves per SIMD) and every wider trip spills more
+#define TILE_T8 1       // ... for groups of five to eight beams
 #endif
 namespace {
 
@@ -151,6 +152,14 @@ __device__ __forceinline__ void tile_trip(const PfTileG* __restrict__ cg, const 
             if ((threadIdx.x & 63) == 0) atomicAdd(&stats[8 + min(max(x1 - x0, y1 - y0), 23)], (unsigned long long)N);
         }
     }
+#if TILE_EXP == 5
+    if (all_coop) {
+#pragma unroll
+        for (int q = 0; q < T; ++q) sum += (int)(src4[q] ^ onehot[q]) + voff[q] + (int)col[q].lza[N - 1];
+        cnt += T * N;
+        return;
+    }
+#endif
     if (__builtin_expect(all_coop, 1)) {
         unsigned v[T][N];
 #pragma unroll
@@ -204,28 +213,21 @@ __device__ __forceinline__ void tile_trip(const PfTileG* __restrict__ cg, const 
     }
 }
 
-// One phase: the groups [g0, g1) all have N beams and go T = tile_t(N) to a trip. The trips of the whole list are
-// numbered through (slot0 = the number of this phase's first trip) and trip j belongs to chunk j % gridDim.y, so
-// every chunk gets the same number of trips of every size to within one; a phase's last trip may be short and is
-// then walked group by group.
+// One phase: the chunk's groups [g0, g1) all have N beams and go T = tile_t(N) to a trip; what is left at the end
+// (the short last trip of a count, which belongs to one chunk) is walked group by group.
 __host__ __device__ constexpr int tile_t(int N) { return N > 4 ? TILE_T8 : TILE_T; }
 template <int N, bool STATS>
-__device__ __forceinline__ void tile_phase(const PfTileG* __restrict__ cg, const PfColG* __restrict__ cgz, int g0, int g1, int& slot0,
+__device__ __forceinline__ void tile_phase(const PfTileG* __restrict__ cg, const PfColG* __restrict__ cgz, int g0, int g1,
                                            const TileLane& L, const TileGrid& G, const PfGridParams& gp,
                                            const uint8_t* __restrict__ lin, __amdgpu_buffer_rsrc_t rsrc,
                                            const double* __restrict__ sorted, int lanes,
                                            int al, bool coop_ok, int& sum, int& cnt, unsigned (&st)[4],
                                            unsigned long long* __restrict__ stats) {
     constexpr int T = tile_t(N);
-    const int C = (int)gridDim.y, y = (int)blockIdx.y;
-    const int nslots = (g1 - g0 + T - 1) / T;
-    for (int sl = (y - slot0 % C + C) % C; sl < nslots; sl += C) {
-        const int ga = g0 + sl * T, gb = min(ga + T, g1);
-        if (gb - ga == T) tile_trip<N, T, STATS>(cg, cgz, ga, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats);
-        else
-            for (int g = ga; g < gb; ++g) tile_trip<N, 1, STATS>(cg, cgz, g, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats);
-    }
-    slot0 += nslots;
+    int g = g0;
+    for (; g + T <= g1; g += T) tile_trip<N, T, STATS>(cg, cgz, g, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats);
+    if (T > 1)
+        for (; g < g1; ++g) tile_trip<N, 1, STATS>(cg, cgz, g, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats);
 }
 
 // STATS (SLAM_PF_TILE_STATS=1, development aid): stats[0..3] += wave-beams by window load / the other ways / of groups
@@ -233,21 +235,36 @@ __device__ __forceinline__ void tile_phase(const PfTileG* __restrict__ cg, const
 template <bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_measure_tile(
         const double* __restrict__ sorted, int lanes, const int32_t* __restrict__ order,
-        const uint8_t* __restrict__ shadow, const uint8_t* __restrict__ lin, PfSwz sw, const PfTileG* __restrict__ cg, const PfColG* __restrict__ cgz, int4 ends, int4 ends2, int lzmin, int lzmax,
+        const uint8_t* __restrict__ shadow, const uint8_t* __restrict__ lin, PfSwz sw, const PfTileG* __restrict__ tab, const PfColG* __restrict__ cgz, int lzmin, int lzmax,
         PfGridParams gp, double lmax, int2* __restrict__ partial, unsigned long long* __restrict__ stats) {
     __builtin_amdgcn_s_setprio(3);
+    // this chunk's record of the table in front of the list (wave-uniform: scalar loads): the ends of its groups with
+    // 8, 7, ..., 1 beams and its start. The list is chunk-major (pf_set_beams), so a wave walks contiguous memory and
+    // divides nothing (dealing the trips to the chunks in the kernel cost sixteen scalar divisions per wave)
+    const int32_t* __restrict__ row = (const int32_t*)(tab + blockIdx.y);
+    const int4 ends = make_int4(row[0], row[1], row[2], row[3]), ends2 = make_int4(row[4], row[5], row[6], row[7]);
+    const int gstart = row[PF_TILE_GROUP];
+    const PfTileG* __restrict__ cg = tab + gridDim.y;
     const int lane_id = blockIdx.x * 256 + threadIdx.x;
     // a hole of the lane order (order[] = -1: the padding that starts every z class on a wave boundary)
     // stands in for the wave's first real lane, so that all 64 lanes take part in the window loads; a wave
     // of holes only has nothing to do
     const int who = lane_id < lanes ? order[lane_id] : -1;
+    TileLane L;
+    L.rd = min(lane_id, lanes - 1);
+    // the rows are loaded before order[] is known (one memory round trip for the prologue, not two); only a wave with
+    // holes loads them again, from its first real lane
+    double c = sorted[L.rd], s = sorted[(size_t)lanes + L.rd];
+    double tx = sorted[2 * (size_t)lanes + L.rd], ty = sorted[3 * (size_t)lanes + L.rd];
+    double tz = sorted[4 * (size_t)lanes + L.rd];
     const unsigned long long vm = __ballot(who >= 0);
     if (vm == 0ull) return;
-    TileLane L;
-    L.rd = who >= 0 ? lane_id : (lane_id & ~63) + (__ffsll((long long)vm) - 1);
-    const double c = sorted[L.rd], s = sorted[(size_t)lanes + L.rd];
-    const double tx = sorted[2 * (size_t)lanes + L.rd], ty = sorted[3 * (size_t)lanes + L.rd];
-    const double tz = sorted[4 * (size_t)lanes + L.rd];
+    if (vm != ~0ull) {
+        L.rd = who >= 0 ? lane_id : (lane_id & ~63) + (__ffsll((long long)vm) - 1);
+        c = sorted[L.rd]; s = sorted[(size_t)lanes + L.rd];
+        tx = sorted[2 * (size_t)lanes + L.rd]; ty = sorted[3 * (size_t)lanes + L.rd];
+        tz = sorted[4 * (size_t)lanes + L.rd];
+    }
     const float cf = (float)c, sf = (float)s;
     L.rotA = v2f_t{cf, sf}; L.rotB = v2f_t{-sf, cf};
     L.trh = v2f_t{(float)(tx + 0.5), (float)(ty + 0.5)};
@@ -288,9 +305,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     unsigned st[4] = {0, 0, 0, 0};
     // priority follows progress (k_measure_col: the issue arbiter favours the oldest wave, which staggers the
     // finish times of a launch that is one residency deep)
-    int slot0 = 0;
-#define TILE_PHASE(N, G0, G1) tile_phase<N, STATS>(cg, cgz, G0, G1, slot0, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats)
-    TILE_PHASE(8, 0, ends.x);
+#if TILE_EXP == 4
+#define TILE_PHASE(N, G0, G1) sum += (G1) - (G0)
+#else
+#define TILE_PHASE(N, G0, G1) tile_phase<N, STATS>(cg, cgz, G0, G1, L, G, gp, lin, rsrc, sorted, lanes, al, coop_ok, sum, cnt, st, stats)
+#endif
+    TILE_PHASE(8, gstart, ends.x);
     TILE_PHASE(7, ends.x, ends.y);
     TILE_PHASE(6, ends.y, ends.z);
     TILE_PHASE(5, ends.z, ends.w);
@@ -312,21 +332,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 }  // namespace
 
-int pfk_tile_slot() { return TILE_T; }
+int pfk_tile_trip(int n_beams) { return tile_t(n_beams); }
 static_assert(PF_TILE_GROUP == 8, "k_measure_tile has eight phases");
 
 hipError_t pfk_measure_tile(hipStream_t st, const double* sorted, int lanes, const int32_t* order,
-                            const uint8_t* shadow, const uint8_t* lin, PfSwz sw, const PfTileG* cg, const PfColG* cgz, const int group_ends[PF_TILE_GROUP],
+                            const uint8_t* shadow, const uint8_t* lin, PfSwz sw, const PfTileG* cg, const PfColG* cgz,
                             int lzmin, int lzmax, int n_chunks, PfGridParams gp, double lmax, int2* partial) {
     static const bool want_stats = getenv("SLAM_PF_TILE_STATS") != nullptr;
     const dim3 grid((lanes + 255) / 256, n_chunks);
-    const int4 ends = make_int4(group_ends[0], group_ends[1], group_ends[2], group_ends[3]);
-    const int4 ends2 = make_int4(group_ends[4], group_ends[5], group_ends[6], group_ends[7]);
     if (want_stats) {
         unsigned long long* stats = nullptr;
         if (hipMalloc((void**)&stats, 256) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(stats, 0, 256, st);
-        hipLaunchKernelGGL(k_measure_tile<true>, grid, dim3(256), 0, st, sorted, lanes, order, shadow, lin, sw, cg, cgz, ends, ends2, lzmin,
+        hipLaunchKernelGGL(k_measure_tile<true>, grid, dim3(256), 0, st, sorted, lanes, order, shadow, lin, sw, cg, cgz, lzmin,
                            lzmax, gp, lmax, partial, stats);
         unsigned long long hs[32];
         (void)hipStreamSynchronize(st);
@@ -339,7 +357,7 @@ hipError_t pfk_measure_tile(hipStream_t st, const double* sorted, int lanes, con
         fprintf(stderr, "\n");
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_measure_tile<false>, grid, dim3(256), 0, st, sorted, lanes, order, shadow, lin, sw, cg, cgz, ends, ends2, lzmin,
+    hipLaunchKernelGGL(k_measure_tile<false>, grid, dim3(256), 0, st, sorted, lanes, order, shadow, lin, sw, cg, cgz, lzmin,
                        lzmax, gp, lmax, partial, (unsigned long long*)nullptr);
     return hipGetLastError();
 }

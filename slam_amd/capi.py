@@ -351,7 +351,7 @@ class Handle:
         return out[:n.value].copy(), total.value
 
     def sequential_cdf(self, w, how=1):
-        """S3P:763-767 on any weight vector: float64 [n+1]. how=0 one-lane chain, how=1 workgroup scan."""
+        """S3P:763-767 on any weight vector: float64 [n+1]. how=0 one-lane chain, how=1 workgroup scan, how=2 many workgroups."""
         w = _c(w, np.float64).reshape(-1)
         out = np.empty(w.size + 1, np.float64)
         self._ck(lib().pf_sequential_cdf(self._h, _p(w), C.c_int64(w.size), C.c_int32(how), _p(out)),

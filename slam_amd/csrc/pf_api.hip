@@ -777,9 +777,11 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     {
         // one allocation, carved: 6 double arrays of nb (+8 for prm), 2 int2 arrays, 1 int array, ndup
         const size_t nb = (Pg + 255) / 256;
-        const size_t bytes = sizeof(double) * (8 + 5 * nb) + sizeof(int2) * 2 * nb + sizeof(int32_t) * (nb + 4);
+        const size_t seg_bytes = 128 * ((size_t)Pg / 8192 + 2);
+        const size_t bytes = seg_bytes + sizeof(double) * (8 + 5 * nb) + sizeof(int2) * 2 * nb + sizeof(int32_t) * (nb + 4);
         CREATE_TRY(hipMalloc(&h->rs_mem, bytes));
         char* q = (char*)h->rs_mem;
+        h->rs.segs = (void*)q; q += seg_bytes;
         h->rs.prm = (double*)q; q += sizeof(double) * 8;
         h->rs.bsum = (double*)q; q += sizeof(double) * nb;
         h->rs.bmax = (double*)q; q += sizeof(double) * nb;
@@ -1790,14 +1792,16 @@ static int grow_scratch(pf_handle* h, size_t need) {
 int pf_sequential_cdf(pf_handle* h, const double* w, int64_t n, int32_t how, double* cdf_out) {
     if (!h) return PF_ERR_ARG;
     NEED(h, w && cdf_out && n >= 1 && n <= (int64_t)1 << 30, "null argument / n outside 1..2^30");
-    NEED(h, how == 0 || how == 1, "how");
+    NEED(h, how == 0 || how == 1 || how == 2, "how");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t nb_w = sizeof(double) * (size_t)n, nb_c = sizeof(double) * ((size_t)n + 1);
-    if (int rc = grow_scratch(h, up256(nb_w) + nb_c)) return rc;
+    const size_t nb_s = how == 2 ? pfk_cdf_scratch_bytes((int)n) : 0;
+    if (int rc = grow_scratch(h, up256(nb_w) + up256(nb_c) + nb_s)) return rc;
     double* d_w = (double*)h->vote_scratch;
     double* d_c = (double*)(h->vote_scratch + up256(nb_w));
+    void* d_s = (void*)(h->vote_scratch + up256(nb_w) + up256(nb_c));
     HIP_TRY(h, hipMemcpyAsync(d_w, w, nb_w, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, pfk_cdf_of(h->stream, d_w, (int)n, d_c, how));
+    HIP_TRY(h, pfk_cdf_of(h->stream, d_w, (int)n, d_c, how, d_s));
     HIP_TRY(h, hipMemcpyAsync(cdf_out, d_c, nb_c, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return PF_OK;

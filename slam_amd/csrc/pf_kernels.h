@@ -220,6 +220,7 @@ struct PfResampleScratch {
     int2* boff2;        // [nb]
     int32_t* bbest_i;   // [nb]
     int32_t* ndup;      // [1]
+    void* segs;         // [Pg / 8192 + 2] records of 128 B: the segments of the many-workgroup sequential-order CDF (k_cdfx_*)
 };
 
 struct PfUpdateWork;
@@ -272,7 +273,8 @@ int32_t pfk_result_best(const unsigned long long* slot, int32_t prev);
 // one-lane chain, how = 1 the workgroup scan that gives the same bits (k_cdf_exact_if's form)
 // text pf_last_error(NULL) returns (errors of calls that have no handle)
 void pfk_set_global_error(const char* text);
-hipError_t pfk_cdf_of(hipStream_t st, const double* w, int n, double* cdf, int how);
+hipError_t pfk_cdf_of(hipStream_t st, const double* w, int n, double* cdf, int how, void* scratch = nullptr);
+size_t pfk_cdf_scratch_bytes(int n);     // device scratch of how = 2 (the many-workgroup form)
 // resample() on its own (weights given by the caller): sequential-order CDF + K4's initial state
 hipError_t pfk_resample_prepare(hipStream_t st, const double* w, int Pg, double* cdf, int32_t* first,
                                 unsigned long long* counters);

@@ -26,6 +26,7 @@
 #define NEVER_DRAWN 0x7f7f7f7f   // "nobody drew this slot": larger than any slot number
 #define PF_MID_MAX 16384         // limit of the one-workgroup forms k3_mid / k4_mid
 #define PF_FOLD_CDF_MAX 32768     // up to here k_first_c rebuilds an ambiguous step's CDF itself
+#define PF_MULTI_CDF_MIN 65536    // from here on the sequential-order CDF is rebuilt by many workgroups (k_cdfx_*)
 
 // prm[] layout (device doubles)
 #define PRM_K99 0      // 0.99 * smallest sum (S3P:928)
@@ -327,15 +328,17 @@ __device__ __forceinline__ void x_round_pairs(const double (&wk)[XE], double sca
     if (my_lim == lim) { cdf[lim + 1] = r_stop; *s_sh = r_stop; *pos_sh = lim + 1; }
 }
 
-// tile: XCHAIN doubles of LDS. blockDim.x == WG.
-__device__ __forceinline__ void par_seq_cdf(const double* w, int n, double* cdf, double* tile) {
+// tile: XCHAIN doubles of LDS. blockDim.x == WG. The elements [pos0, n) behind a running sum s0 (= cdf[pos0], already
+// stored); returns the running sum at n (the same value in every thread).
+__device__ __forceinline__ double par_seq_range(const double* w, int pos0, double s0, int n, double* cdf, double* tile) {
     __shared__ IncPair wtot[WG / WAVE];
     __shared__ double wsum[WG / WAVE];
     __shared__ double s_sh;
     __shared__ int pos_sh, lim_sh, tie_sh;
     __shared__ double xpose[(WG / WAVE) * XT];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) { cdf[0] = 0.0; s_sh = 0.0; pos_sh = 0; tie_sh = 0; }
+    __syncthreads();
+    if (tid == 0) { s_sh = s0; pos_sh = pos0; tie_sh = 0; }
     __syncthreads();
     while (true) {
         const int pos = pos_sh;
@@ -449,6 +452,11 @@ __device__ __forceinline__ void par_seq_cdf(const double* w, int n, double* cdf,
         }
         __syncthreads();
     }
+    return s_sh;
+}
+__device__ __forceinline__ void par_seq_cdf(const double* w, int n, double* cdf, double* tile) {
+    if (threadIdx.x == 0) cdf[0] = 0.0;
+    (void)par_seq_range(w, 0, 0.0, n, cdf, tile);
 }
 
 // Sequential-order CDF of the current weights, only when counters[1] (ambiguous draws) != 0.
@@ -464,6 +472,230 @@ __global__ __launch_bounds__(WG) void k_cdf_of(const double* w, int n, double* c
     __shared__ double tile[TILE];
     if (how == 0) seq_cdf(w, n, cdf, tile);
     else par_seq_cdf(w, n, cdf, tile);
+}
+
+// The same CDF by MANY workgroups (a million particles: one workgroup takes a millisecond, and on a sharded job every
+// rank pays it in every step). A segment of XSEG elements whose running sum stays inside one binade is, by the
+// argument above, a function of the sum's parity when it enters: (total increment on even, on odd), composed from its
+// elements' pairs in index order. Which binade a segment lies in is GUESSED from an approximate CDF at its two ends (the
+// parallel CDF the weight kernels left, or plain segment sums), with a margin far above the two CDFs' difference:
+//   k_cdfx_summ  every segment but the first: the guess, and the segment's pair for the guessed binade;
+//   k_cdfx_walk  one workgroup walks the segments in order with the EXACT running sum: a segment whose guess holds for
+//                that sum (same binade on entry, still inside it on exit, every element of the scannable form) is
+//                settled by one addition and left to the third kernel; any other (the first segment, the dozen or so that
+//                cross a binade, sums that are tiny, negative or not finite) is done on the spot by par_seq_range;
+//   k_cdfx_fill  the settled segments, each from its exact entry value, in parallel.
+// Nothing rests on the guess being right: the walker tests it against the exact sum, and a wrong guess only sends the
+// segment down the slow way. Bit-identical to seq_cdf (tests/test_gpu_parity.py).
+#define XSEG (WG * XE)
+#define XWALK 256                     // segment records the walker stages in LDS at a time
+#define XGUESS 1.4901161193847656e-08          // 2^-26: margin of the binade guess (the two CDFs differ by < n * 2^-52 relative)
+// state: 0 not scannable / done by the walker; 1 guessed: one binade; 2 to fill (one binade); 3 guessed: one crossing at
+// element p (the elements before it in binade ex, pair (e, o); p itself added in hardware; the elements behind it in
+// binade ex + 1, pair (e2, o2)); 4 to fill (crossing)
+struct __attribute__((aligned(64))) CdfSeg { double e, o, start, e2, o2, start2, wp; int ex, state, p, pad; };
+// the workgroup's elements' pairs composed in index order: the exclusive prefix of this thread (ex) and the total
+__device__ __forceinline__ void cdfx_block_scan(IncPair loc, IncPair* wtot, IncPair& ex, IncPair& total) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    IncPair inc = loc;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const IncPair t = shfl_up_pair(inc, o);
+        if (lane >= o) inc = inc_then(t, inc);
+    }
+    const IncPair prev = shfl_up_pair(inc, 1);
+    __syncthreads();
+    if (lane == WAVE - 1) wtot[wv] = inc;
+    __syncthreads();
+    IncPair tot{0.0, 0.0};
+    if (lane < WG / WAVE) tot = wtot[lane];
+#pragma unroll
+    for (int o = 1; o < WG / WAVE; o <<= 1) {
+        const IncPair t = shfl_up_pair(tot, o);
+        if (lane >= o) tot = inc_then(t, tot);
+    }
+    ex = IncPair{0.0, 0.0};
+    if (wv > 0) { ex.e = __shfl(tot.e, wv - 1, WAVE); ex.o = __shfl(tot.o, wv - 1, WAVE); }
+    if (lane > 0) ex = inc_then(ex, prev);
+    total.e = __shfl(tot.e, WG / WAVE - 1, WAVE); total.o = __shfl(tot.o, WG / WAVE - 1, WAVE);
+}
+// cdf: an APPROXIMATE CDF of w (the parallel one of the weight kernels, or k_cdfx_approx's), read here, overwritten later
+__global__ __launch_bounds__(WG) void k_cdfx_summ(const double* __restrict__ w, int n, const double* __restrict__ cdf,
+                                                  CdfSeg* __restrict__ segs, const unsigned long long* counters) {
+    __shared__ IncPair wtot[WG / WAVE];
+    __shared__ int bad_sh, p_sh;
+    if (counters && ld_agent(&counters[1]) == 0) return;
+    const int tid = threadIdx.x, b = blockIdx.x + 1;
+    const int start = b * XSEG, end = (int)min((long long)n, (long long)start + XSEG);
+    const double lo = cdf[start], hi = cdf[end];
+    bool ok = lo >= 0x1p-960 && hi < 0x1p1000 && hi >= lo;
+    const int ex = ok ? ilogb(lo * (1.0 - XGUESS)) : 0;
+    const int exh = ok ? ilogb(hi * (1.0 + XGUESS)) : 0;
+    ok = ok && (exh == ex || exh == ex + 1);
+    bool cross = ok && exh == ex + 1;
+    if (tid == 0) { bad_sh = 0; p_sh = INT_MAX; }
+    __syncthreads();
+    const int base = start + tid * XE;
+    const double edge = ldexp(1.0, ex + 1);                          // where the next binade starts
+    if (cross) {                                                     // (workgroup-uniform) the first element that reaches it
+        int mine = INT_MAX;
+#pragma unroll
+        for (int k = XE - 1; k >= 0; --k)
+            if (base + k < end && cdf[base + k + 1] >= edge) mine = base + k;
+        if (mine != INT_MAX) atomicMin(&p_sh, mine);
+        __syncthreads();
+    }
+    const int p = cross ? p_sh : INT_MAX;
+    // (no element of the guess reaches the edge, only the margin did -- the last segment of normalised weights ends just
+    // below 1: one binade as far as the guess can tell, and the walker sees whether the exact sum stays inside it)
+    if (cross && p == INT_MAX) cross = false;
+    if (cross) {
+        // the guess must be clear of the edge on both sides of p (else the walker takes the segment the slow way)
+        ok = cdf[p] * (1.0 + XGUESS) < edge && cdf[p + 1] * (1.0 - XGUESS) >= edge;
+    }
+    IncPair locA{0.0, 0.0}, locB{0.0, 0.0};
+    if (ok) {                                                        // workgroup-uniform
+        const double scaleA = ldexp(1.0, 52 - ex), scaleB = ldexp(1.0, 51 - ex);
+        bool fine = true;
+#pragma unroll
+        for (int k = 0; k < XE; ++k) {
+            IncPair el{0.0, 0.0};
+            const int idx = base + k;
+            if (idx < end && idx != p) fine = inc_of(w[idx], idx < p ? scaleA : scaleB, false, el) && fine;
+            if (idx < p) locA = inc_then(locA, el); else locB = inc_then(locB, el);
+        }
+        if (!fine) bad_sh = 1;                                       // (benign race: every writer stores 1)
+    }
+    IncPair exq, totalA, totalB{0.0, 0.0};
+    cdfx_block_scan(locA, wtot, exq, totalA);
+    if (cross) cdfx_block_scan(locB, wtot, exq, totalB);             // (workgroup-uniform)
+    if (tid == 0) {
+        CdfSeg sg;
+        sg.e = totalA.e; sg.o = totalA.o; sg.start = 0.0; sg.e2 = totalB.e; sg.o2 = totalB.o; sg.start2 = 0.0;
+        sg.wp = (ok && cross) ? w[p] : 0.0;
+        sg.ex = ex; sg.state = (ok && !bad_sh) ? (cross ? 3 : 1) : 0; sg.p = p; sg.pad = 0;
+        segs[b] = sg;
+    }
+}
+// 2^k for -1022 <= k <= 1023 and the exponent of a normal positive double, without the library calls (the walker does a
+// dozen of them per segment, one thread's worth of latency each)
+__device__ __forceinline__ double x_pow2(int k) { return __longlong_as_double((long long)(1023 + k) << 52); }
+__device__ __forceinline__ int x_exp(double v) { return (int)((__double_as_longlong(v) >> 52) & 0x7ff) - 1023; }
+__global__ __launch_bounds__(WG) void k_cdfx_walk(const double* w, int n, double* cdf, CdfSeg* segs,
+                                                  const unsigned long long* counters) {
+    __shared__ double tile[XCHAIN];
+    __shared__ CdfSeg seg_sh[XWALK];
+    if (counters && ld_agent(&counters[1]) == 0) return;
+    const int nseg = (n + XSEG - 1) / XSEG;
+    if (threadIdx.x == 0) cdf[0] = 0.0;
+    double s = par_seq_range(w, 0, 0.0, min(n, XSEG), cdf, tile);
+    // (the records through LDS, XWALK at a time: one dependent global load per segment was a microsecond each)
+    for (int b = 1; b < nseg; ++b) {
+        if ((b - 1) % XWALK == 0) {
+            __syncthreads();
+            for (int k = threadIdx.x; k < XWALK && b + k < nseg; k += WG) seg_sh[k] = segs[b + k];
+            __syncthreads();
+        }
+        const CdfSeg sg = seg_sh[(b - 1) % XWALK];                   // the same for every thread
+        bool ok = (sg.state == 1 || sg.state == 3) && s >= 0x1p-960 && s < INFINITY && x_exp(s) == sg.ex;
+        double s1 = 0.0, sp = 0.0;
+        if (ok) {
+            const double S0 = s * x_pow2(52 - sg.ex);
+            const double S1 = S0 + (x_odd(S0) ? sg.o : sg.e);
+            ok = S1 < XLIM;                                          // still inside the binade behind the (first) part
+            s1 = S1 * x_pow2(sg.ex - 52);
+        }
+        if (ok && sg.state == 3) {
+            sp = s1 + sg.wp;                                         // the add that crosses, in hardware
+            ok = sp < INFINITY && x_exp(sp) == sg.ex + 1;
+            if (ok) {
+                const double T0 = sp * x_pow2(51 - sg.ex);
+                const double T1 = T0 + (x_odd(T0) ? sg.o2 : sg.e2);
+                ok = T1 < XLIM;
+                s1 = T1 * x_pow2(sg.ex - 51);
+            }
+        }
+        if (ok) {
+            if (threadIdx.x == 0) { segs[b].start = s; segs[b].start2 = sp; segs[b].state = sg.state + 1; }
+            s = s1;
+        } else {
+            if (threadIdx.x == 0) segs[b].state = 0;
+#ifdef CDFX_DEBUG
+            if (threadIdx.x == 0) printf("walker: segment %d of %d the slow way (state %d, ex %d, s %.17g)\n", b, nseg, sg.state, sg.ex, s);
+#endif
+            s = par_seq_range(w, b * XSEG, s, (int)min((long long)n, (long long)(b + 1) * XSEG), cdf, tile);
+        }
+    }
+}
+__global__ __launch_bounds__(WG) void k_cdfx_fill(const double* __restrict__ w, int n, double* __restrict__ cdf,
+                                                  const CdfSeg* __restrict__ segs, const unsigned long long* counters) {
+    __shared__ IncPair wtot[WG / WAVE];
+    if (counters && ld_agent(&counters[1]) == 0) return;
+    const int tid = threadIdx.x, b = blockIdx.x + 1;
+    const CdfSeg sg = segs[b];
+    if (sg.state != 2 && sg.state != 4) return;                      // workgroup-uniform
+    const bool cross = sg.state == 4;
+    const int p = cross ? sg.p : INT_MAX;
+    const int start = b * XSEG, end = (int)min((long long)n, (long long)start + XSEG);
+    const double scaleA = ldexp(1.0, 52 - sg.ex), qA = ldexp(1.0, sg.ex - 52);
+    const double scaleB = ldexp(1.0, 51 - sg.ex), qB = ldexp(1.0, sg.ex - 51);
+    const int base = start + tid * XE;
+    IncPair el[XE];
+    IncPair locA{0.0, 0.0}, locB{0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < XE; ++k) {
+        el[k] = IncPair{0.0, 0.0};
+        const int idx = base + k;
+        if (idx < end && idx != p) (void)inc_of(w[idx], idx < p ? scaleA : scaleB, false, el[k]);
+        if (idx < p) locA = inc_then(locA, el[k]); else locB = inc_then(locB, el[k]);
+    }
+    IncPair exA, exB{0.0, 0.0}, total;
+    cdfx_block_scan(locA, wtot, exA, total);
+    if (cross) cdfx_block_scan(locB, wtot, exB, total);              // (workgroup-uniform)
+    const double S0 = sg.start * scaleA, T0 = sg.start2 * scaleB;
+    double S = S0 + (x_odd(S0) ? exA.o : exA.e);
+    double T = T0 + (x_odd(T0) ? exB.o : exB.e);
+#pragma unroll
+    for (int k = 0; k < XE; ++k) {
+        const int idx = base + k;
+        if (idx < p) { S += x_odd(S) ? el[k].o : el[k].e; if (idx < end) cdf[idx + 1] = S * qA; }
+        else if (idx == p) cdf[idx + 1] = sg.start2;
+        else { T += x_odd(T) ? el[k].o : el[k].e; if (idx < end) cdf[idx + 1] = T * qB; }
+    }
+}
+// an approximate CDF for a weight vector that has none yet (pf_sequential_cdf's how = 2): plain sums of the segments,
+// their running total, a plain scan inside each segment
+__global__ __launch_bounds__(WG) void k_cdfx_segsum(const double* __restrict__ w, int n, double* __restrict__ sums) {
+    __shared__ double sh[WG / WAVE];
+    const int start = blockIdx.x * XSEG, end = (int)min((long long)n, (long long)start + XSEG);
+    double v = 0.0;
+    for (int i = start + threadIdx.x; i < end; i += WG) v += w[i];
+    v = block_sum(v, sh);
+    if (threadIdx.x == 0) sums[blockIdx.x] = v;
+}
+__global__ void k_cdfx_bounds(const double* __restrict__ sums, int nseg, double* __restrict__ bounds) {
+    if (threadIdx.x || blockIdx.x) return;
+    double r = 0.0;
+    bounds[0] = 0.0;
+    for (int b = 0; b < nseg; ++b) { r += sums[b]; bounds[b + 1] = r; }
+}
+__global__ __launch_bounds__(WG) void k_cdfx_approx(const double* __restrict__ w, int n, const double* __restrict__ bounds,
+                                                    double* __restrict__ cdf) {
+    __shared__ double wsum[WG / WAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int start = blockIdx.x * XSEG, end = (int)min((long long)n, (long long)start + XSEG);
+    const int base = start + tid * XE;
+    double v[XE], loc = 0.0;
+#pragma unroll
+    for (int k = 0; k < XE; ++k) { v[k] = base + k < end ? w[base + k] : 0.0; loc += v[k]; }
+    const double inc = wave_scan(loc);
+    if (lane == WAVE - 1) wsum[wv] = inc;
+    __syncthreads();
+    double off = bounds[blockIdx.x] + (inc - loc);
+    for (int k = 0; k < wv; ++k) off += wsum[k];
+    if (blockIdx.x == 0 && tid == 0) cdf[0] = 0.0;
+#pragma unroll
+    for (int k = 0; k < XE; ++k) { off += v[k]; if (base + k < end) cdf[base + k + 1] = off; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -846,9 +1078,13 @@ __device__ inline bool draw_is_ambiguous(double ui, int lo, const double* cdf, i
 __device__ inline void d_search_tail(int i, double ui, int lo, const double* cdf, int Pg, double bound,
                                      int32_t* draw, unsigned long long* counters, const double* top = nullptr) {
     const bool hit = lo <= Pg && cdf[lo - 1] < ui;
-    draw[i] = hit ? lo - 1 : i;
+    const int a = hit ? lo - 1 : i;
     if (!hit) atomicAdd(&counters[0], 1ull);
-    if (bound != 0.0 && (!hit || draw_is_ambiguous(ui, lo, cdf, Pg, bound, top))) atomicAdd(&counters[1], 1ull);
+    // a draw the two orders of summation might settle differently is counted and marked (~a): d_first searches it
+    // again on the sequential-order CDF, which is rebuilt in between when the count is not zero
+    const bool amb = bound != 0.0 && (!hit || draw_is_ambiguous(ui, lo, cdf, Pg, bound, top));
+    if (amb) atomicAdd(&counters[1], 1ull);
+    draw[i] = amb ? ~a : a;
 }
 // The same search in two levels: the CDF at the end of every 256-particle block staged in LDS
 // (XTOP entries at most), bisected there, then the eight probes inside the block that holds the
@@ -891,9 +1127,11 @@ __device__ inline void d_search(int i, const double* cdf, const double* __restri
     if (i >= Pg) return;
     const double ui = u[i];
     bool hit; int lo;
-    draw[i] = search_draw(cdf, ui, i, Pg, hit, lo);
+    const int a = search_draw(cdf, ui, i, Pg, hit, lo);
     if (!hit) atomicAdd(&counters[0], 1ull);
-    if (bound != 0.0 && (!hit || draw_is_ambiguous(ui, lo, cdf, Pg, bound))) atomicAdd(&counters[1], 1ull);
+    const bool amb = bound != 0.0 && (!hit || draw_is_ambiguous(ui, lo, cdf, Pg, bound));
+    if (amb) atomicAdd(&counters[1], 1ull);
+    draw[i] = amb ? ~a : a;
 }
 __global__ __launch_bounds__(NB) void k_search(const double* __restrict__ cdf,
                                                const double* __restrict__ u, int Pg, double bound,
@@ -903,15 +1141,15 @@ __global__ __launch_bounds__(NB) void k_search(const double* __restrict__ cdf,
 }
 
 // first[a] = position of the first draw of ancestor a. When the FAST-order search flagged
-// ambiguous draws, k_cdf_exact_if has rebuilt the CDF in sequential order in between and every
-// draw is searched again here (no-hits recounted in counters[2]).
+// ambiguous draws, the CDF has been rebuilt in sequential order in between and the flagged draws
+// are searched again here (no-hits recounted in counters[2]).
 __device__ inline void d_first(int i, const double* cdf, const double* __restrict__ u, int32_t* draw,
                                int Pg, int32_t* first, unsigned long long* counters) {
     if (i >= Pg) return;
     int a = draw[i];
-    if (ld_agent(&counters[1]) != 0) {
-        bool hit; int lo;
-        a = search_draw(cdf, u[i], i, Pg, hit, lo);
+    if (a < 0) {                                   // marked by the search: only these are searched again (every draw
+        bool hit; int lo;                          // that found no interval is among them, so counters[2] is the step's
+        a = search_draw(cdf, u[i], i, Pg, hit, lo);   // count of those)
         draw[i] = a;
         if (!hit) atomicAdd(&counters[2], 1ull);
     }
@@ -1424,7 +1662,14 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
     if (folded && Pg <= PF_FOLD_CDF_MAX) {
         hipLaunchKernelGGL(k_first_c, dim3(nb), dim3(NB), 0, st, (double*)cdf, u, draw, Pg, w, first, counters);
     } else {
-        if (bound > 0.0)
+        if (bound > 0.0 && Pg >= PF_MULTI_CDF_MIN && sc.segs) {
+            // the sequential-order CDF by many workgroups (each of the three returns at once when no draw was flagged)
+            const int nseg = (Pg + XSEG - 1) / XSEG;
+            CdfSeg* segs = (CdfSeg*)sc.segs;
+            hipLaunchKernelGGL(k_cdfx_summ, dim3(nseg - 1), dim3(WG), 0, st, w, Pg, cdf, segs, counters);
+            hipLaunchKernelGGL(k_cdfx_walk, dim3(1), dim3(WG), 0, st, w, Pg, (double*)cdf, segs, counters);
+            hipLaunchKernelGGL(k_cdfx_fill, dim3(nseg - 1), dim3(WG), 0, st, w, Pg, (double*)cdf, segs, counters);
+        } else if (bound > 0.0)
             hipLaunchKernelGGL(k_cdf_exact_if, dim3(1), dim3(WG), 0, st, w, Pg, (double*)cdf, counters);
         hipLaunchKernelGGL(k_first, dim3(nb), dim3(NB), 0, st, cdf, u, draw, Pg, first, counters);
     }
@@ -1497,7 +1742,24 @@ hipError_t pfk_resample_prepare(hipStream_t st, const double* w, int Pg, double*
     return hipGetLastError();
 }
 
-hipError_t pfk_cdf_of(hipStream_t st, const double* w, int n, double* cdf, int how) {
+size_t pfk_cdf_scratch_bytes(int n) { const size_t nseg = ((size_t)n + XSEG - 1) / XSEG; return (nseg + 1) * sizeof(CdfSeg) + (2 * nseg + 2) * sizeof(double); }
+hipError_t pfk_cdf_of(hipStream_t st, const double* w, int n, double* cdf, int how, void* scratch) {
+    if (how == 2) {                                             // the many-workgroup form (scratch: pfk_cdf_scratch_bytes)
+        const int nseg = (n + XSEG - 1) / XSEG;
+        CdfSeg* segs = (CdfSeg*)scratch;
+        double* sums = (double*)(segs + nseg + 1);
+        double* bounds = sums + nseg;
+        if (nseg > 1) {
+            hipLaunchKernelGGL(k_cdfx_segsum, dim3(nseg), dim3(WG), 0, st, w, n, sums);
+            hipLaunchKernelGGL(k_cdfx_bounds, dim3(1), dim3(64), 0, st, sums, nseg, bounds);
+            hipLaunchKernelGGL(k_cdfx_approx, dim3(nseg), dim3(WG), 0, st, w, n, bounds, cdf);
+            hipLaunchKernelGGL(k_cdfx_summ, dim3(nseg - 1), dim3(WG), 0, st, w, n, cdf, segs, (const unsigned long long*)nullptr);
+        }
+        hipLaunchKernelGGL(k_cdfx_walk, dim3(1), dim3(WG), 0, st, w, n, cdf, segs, (const unsigned long long*)nullptr);
+        if (nseg > 1)
+            hipLaunchKernelGGL(k_cdfx_fill, dim3(nseg - 1), dim3(WG), 0, st, w, n, cdf, segs, (const unsigned long long*)nullptr);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_cdf_of, dim3(1), dim3(WG), 0, st, w, n, cdf, how);
     return hipGetLastError();
 }

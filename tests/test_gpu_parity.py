@@ -286,6 +286,19 @@ def test_workgroup_cdf_is_the_sequential_cdf_bit_for_bit():
     cases["negative_sum"] = neg
     cases["denormals"] = np.concatenate([[5e-324] * 100, rng.random(5000) * 1e-310, [1.0], [5e-324] * 100])
     cases["huge_after_small"] = np.concatenate([rng.random(10000) * 1e-5, [1e200], rng.random(10000), [1e308, 1e308]])
+    # the many-workgroup form at the size it is for: a million normalised weights (about ten binade crossings behind the
+    # first segment), a flat million, ties spread over every segment, a segment boundary exactly on a binade crossing,
+    # and elements the scan cannot take in the middle of otherwise clean segments
+    w = rng.random(1000000) + 1e-3; cases["normalised_1000000"] = w / w.sum()
+    cases["flat_1048576"] = np.full(1 << 20, 2.0 ** -20)
+    k = rng.integers(1, 1 << 10, 200000).astype(np.float64)
+    cases["ties_many_segments"] = np.concatenate([[0.5], k * 2.0 ** -54])
+    cases["crossing_on_segment_boundary"] = np.concatenate([np.full(8192, 2.0 ** -14), np.full(8192, 2.0 ** -14), rng.random(30000) * 2.0 ** -16])
+    a = (rng.random(100000) + 0.5) / 100000
+    a[8192 * 3 + 17] = -1e-9; a[8192 * 5] = np.nan
+    cases["bad_elements_inside_segments"] = a
+    a = (rng.random(100000) + 0.5) / 100000; a[8192 * 4 + 5000] = 3.0
+    cases["jump_inside_segment"] = a
     h = capi.Handle(_shared_cfg(64, (16, 16, 16)))
     try:
         for name, w in cases.items():
@@ -293,6 +306,8 @@ def test_workgroup_cdf_is_the_sequential_cdf_bit_for_bit():
                 ref = np.concatenate([[0.0], np.cumsum(w)])                  # sequential, index order
             par = h.sequential_cdf(w, how=1)
             assert np.array_equal(_bits(par), _bits(ref)) or _same_bits_nan(par, ref), name
+            multi = h.sequential_cdf(w, how=2)                               # the many-workgroup form (8192-element segments)
+            assert np.array_equal(_bits(multi), _bits(ref)) or _same_bits_nan(multi, ref), name + " (many workgroups)"
             if w.size <= 100000:
                 chain = h.sequential_cdf(w, how=0)
                 assert np.array_equal(_bits(chain), _bits(ref)) or _same_bits_nan(chain, ref), name

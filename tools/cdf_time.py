@@ -11,7 +11,7 @@ h = capi.Handle(cfg)
 rng = np.random.default_rng(0)
 for n in (8000, 80000, 1000000):
     w = rng.random(n) + 1e-3; w /= w.sum()
-    for how in (1, 1, 0):
+    for how in (1, 1, 2, 2, 0):
         if how == 0 and n > 100000:
             continue
         h.sequential_cdf(w, how)

@@ -230,27 +230,39 @@ def exchange_self_check(capi, ShardedBackend, dist, cfg, sc, Pg, stream):
             and np.array_equal(a0[4], a1[4]) and np.array_equal(a0[5], a1[5]))
 
 
-def k1_traffic(P, M, grid):
-    """HBM-side bytes per K1 launch from the committed PMC passes (profiles/r2_k1_traffic.json,
-    made by tools/pmc_k1.sh), or None when this run is not the workload they were taken on."""
+K1_TRAFFIC_FILE = "profiles/r3_k1_traffic.json"          # committed rocprofv3 --pmc passes (tools/pmc_k1.sh + tools/mk_traffic_json.py)
+K1_STATS_FILE = "profiles/r3_kernel_stats.csv"           # committed rocprofv3 --kernel-trace --stats summary of this command
+
+
+def k1_counters(P, M, grid):
+    """What the committed counter passes say about K1 (HBM-side bytes per launch, L2 hit rate), or {} when this run is not
+    the workload they were taken on. They are NOT measured in this run: a --pmc pass is a run of its own."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_k1_traffic.json")) as f:
+        with open(os.path.join(ROOT, K1_TRAFFIC_FILE)) as f:
             t = json.load(f)
-    except OSError:
-        return None
+    except (OSError, ValueError):
+        return {}
     if (P, M, grid) != (10000, 4096, 256):
-        return None
-    return t["traffic_bytes_per_launch"]
+        return {}
+    return {"traffic": t.get("traffic_bytes_per_launch"), "l2_hit_rate": t.get("l2_hit_rate"),
+            "counters_source": f"{K1_TRAFFIC_FILE} (committed rocprofv3 --pmc passes on this kernel, {t.get('kernel')}; not measured in this run)"}
 
 
-def k1_l2_hit(P, M, grid):
-    """L2 (TCC) hit rate of K1 from the same committed PMC passes, or None."""
+def k1_rocprof_fraction(k1_bytes, P, M, grid):
+    """K1's roofline fraction by rocprofv3's average kernel duration in the committed summary of this command."""
+    if (P, M, grid) != (10000, 4096, 256):
+        return {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_k1_traffic.json")) as f:
-            t = json.load(f)
-    except OSError:
-        return None
-    return t.get("l2_hit_rate") if (P, M, grid) == (10000, 4096, 256) else None
+        import csv
+        with open(os.path.join(ROOT, K1_STATS_FILE)) as f:
+            for r in csv.DictReader(f):
+                if "k_measure_tile" in r["Name"] and int(r["Calls"]) > 1000:
+                    us = float(r["AverageNs"]) / 1e3
+                    return {"frac_rocprof": k1_bytes / (us * 1e-6) / 8e12, "avg_launch_us_rocprof": us,
+                            "rocprof_source": f"{K1_STATS_FILE} (committed rocprofv3 --kernel-trace --stats of python bench.py)"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return {}
 
 
 def stream_copy_gbps(device, mib=1024, reps=10):
@@ -700,9 +712,10 @@ def main():
                        "results_read": "every step, before the next is enqueued" if a.no_pipeline
                                        else "every step, one step late (pf_resample_async)",
                        "ambiguous_draws": int(amb_total), "nohit_draws": int(nohit_total)},
-            "roofline": {"bound": "hbm", "kernel": "k_measure_col", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_measure_tile", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": k1_traffic(P, M, a.grid), "l2_hit_rate": k1_l2_hit(P, M, a.grid),
+                         "traffic": None, "l2_hit_rate": None,
+                         **k1_counters(P, M, a.grid), **k1_rocprof_fraction(k1_bytes, P, M, a.grid),
                          "measured_stream_copy": stream_copy_gbps(f"cuda:{local_rank}"),
                          "algorithmic_bytes_per_launch": k1_bytes,
                          "avg_launch_us": k1_avg_s * 1e6, "launches": int(k1_n),

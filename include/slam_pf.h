@@ -299,7 +299,7 @@ int pf_read_occupied(pf_handle* h, int32_t particle, int32_t threshold, int32_t 
  * cdf_out[0] = 0, cdf_out[i+1] = cdf_out[i] + w[i] in index order, fp64, for any host vector w[n]
  * (cdf_out: host double [n+1]). how = 0: one lane adds in order, the loop as the reference wrote it;
  * how = 1: the workgroup-wide form pf_resample uses to settle draws on CDF boundaries at particle
- * counts where the chain would cost milliseconds; how = 2: the same chain by many workgroups (from 65 536
+ * counts where the chain would cost milliseconds; how = 2: the same chain by many workgroups (from 262 144
  * particles on: segments of 8192 weights summarised as functions of the running sum's parity, one workgroup
  * walking the segments with the exact sum, the others filling them in). All return the same bits for every
  * input (zeros, ties, negative and non-finite weights included); exported so that this can be checked directly. */

@@ -1269,8 +1269,11 @@ bool box_eligible(const pf_handle* h) {
 static PfOrderParams order_params(const pf_handle* h) {
     PfOrderParams op{200.0, 3.0, 3.0, 1, h->P <= 65536 ? 4 : 5, 0, nullptr};
     // k_measure_tile: the top three key bits are the z class (one round(z/res) per wave), the Morton part
-    // has a bit less per axis over the same extent (cells of 1/100 rad and 2/3 voxel)
-    if (h->zsplit) op = PfOrderParams{200.0, 1.5, 1.5, 1, h->P <= 65536 ? 4 : 5, 1, nullptr};
+    // has a bit less per axis over the same extent (cells of 1/100 rad and 2/3 voxel). 12-bit keys at every
+    // particle count: the cells follow the cloud's extent, so 4096 of them order 125 k particles as well for K1 as
+    // 32768 did (0.693 against 0.687 ms at configs[2]'s share) and the ordering is one launch with LDS counters
+    // instead of three with global ones (34 against 120 us there)
+    if (h->zsplit) op = PfOrderParams{200.0, 1.5, 1.5, 1, 4, 1, nullptr};
     static const bool fixed_cells = getenv("SLAM_PF_ORDER_FIXED") != nullptr;    // (comparison: cells that do not follow the cloud)
     if (!fixed_cells && h->ext_cur >= 0) op.ext = h->order_ext + PF_EXT_WORDS * h->ext_cur;
     // k_measure_box wants its workgroups' particles close in yaw (the box of a cluster grows with

@@ -26,7 +26,9 @@
 #define NEVER_DRAWN 0x7f7f7f7f   // "nobody drew this slot": larger than any slot number
 #define PF_MID_MAX 16384         // limit of the one-workgroup forms k3_mid / k4_mid
 #define PF_FOLD_CDF_MAX 32768     // up to here k_first_c rebuilds an ambiguous step's CDF itself
-#define PF_MULTI_CDF_MIN 65536    // from here on the sequential-order CDF is rebuilt by many workgroups (k_cdfx_*)
+#define PF_MULTI_CDF_MIN 262144   // from here on the sequential-order CDF is rebuilt by many workgroups (k_cdfx_*): three launches that
+                                  // cost 16 us when no draw was flagged against the one guard launch's 7, so only where most steps
+                                  // have flagged draws (at 125 k one step in forty has, and the one-workgroup form takes 0.2 ms there)
 
 // prm[] layout (device doubles)
 #define PRM_K99 0      // 0.99 * smallest sum (S3P:928)

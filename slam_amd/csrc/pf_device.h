@@ -132,7 +132,9 @@ __device__ inline void d5_hits_wave(int i, const PfUpdateWork& uw) {
 // S3P:664-704 for ray r: PF_RAY_LANES lanes per ray (two rays per wave: a ray of the 3 m range has
 // at most 60 steps, and half as many waves fit the chip in one residency instead of two and a
 // half); lane l takes steps j = 1+l, 1+l+PF_RAY_LANES, ... (S3P:685: j = 1 .. n_it-1).
+#ifndef PF_RAY_LANES
 #define PF_RAY_LANES 32
+#endif
 #define PF_RAYS_PER_WG (256 / PF_RAY_LANES)
 __device__ inline void d5_rays(int r, int lane, const PfUpdateWork& uw) {
     const PfUpdateParams& up = uw.up;

@@ -34,7 +34,7 @@
 #include <stdlib.h>
 
 #ifndef TILE_EXP
-#define TILE_EXP 0      // development: 1 no window loads, 2 no ds_bpermute, 3 neither, 4 prologue and epilogue only, 5 no work per beam
+#define TILE_EXP 0      // development: 1 no window loads, 2 no ds_bpermute, 3 neither, 4 prologue and epilogue only, 5 no work per beam, 6 nothing at all
                         // (wrong results, timing only)
 #endif
 #ifndef TILE_T
@@ -237,6 +237,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const double* __restrict__ sorted, int lanes, const int32_t* __restrict__ order,
         const uint8_t* __restrict__ shadow, const uint8_t* __restrict__ lin, PfSwz sw, const PfTileG* __restrict__ tab, const PfColG* __restrict__ cgz, int lzmin, int lzmax,
         PfGridParams gp, double lmax, int2* __restrict__ partial, unsigned long long* __restrict__ stats) {
+#if TILE_EXP == 6
+    return;                                          // (an empty launch of the same grid)
+#endif
     __builtin_amdgcn_s_setprio(3);
     // this chunk's record of the table in front of the list (wave-uniform: scalar loads): the ends of its groups with
     // 8, 7, ..., 1 beams and its start. The list is chunk-major (pf_set_beams), so a wave walks contiguous memory and

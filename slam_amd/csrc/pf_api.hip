@@ -777,7 +777,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     {
         // one allocation, carved: 6 double arrays of nb (+8 for prm), 2 int2 arrays, 1 int array, ndup
         const size_t nb = (Pg + 255) / 256;
-        const size_t seg_bytes = 128 * ((size_t)Pg / 8192 + 2);
+        const size_t seg_bytes = 128 * ((size_t)Pg / 8192 + 6);
         const size_t bytes = seg_bytes + sizeof(double) * (8 + 5 * nb) + sizeof(int2) * 2 * nb + sizeof(int32_t) * (nb + 4);
         CREATE_TRY(hipMalloc(&h->rs_mem, bytes));
         char* q = (char*)h->rs_mem;

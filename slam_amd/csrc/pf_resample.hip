@@ -492,6 +492,16 @@ __global__ __launch_bounds__(WG) void k_cdf_of(const double* w, int n, double* c
 #define XSEG (WG * XE)
 #define XWALK 256                     // segment records the walker stages in LDS at a time
 #define XGUESS 1.4901161193847656e-08          // 2^-26: margin of the binade guess (the two CDFs differ by < n * 2^-52 relative)
+// The segments: [0, XCHAIN) (the binades change every few elements there: always the one-lane chain), [1024, 2048),
+// [2048, 4096), [4096, 8192) (one binade crossing each on an even CDF), then XSEG elements each.
+#define XHEAD 4                        // segments inside the first XSEG elements
+__host__ __device__ inline int cdfx_nseg(long long n) { return n <= XSEG ? XHEAD : XHEAD - 1 + (int)((n + XSEG - 1) / XSEG); }
+__host__ __device__ inline void cdfx_range(int b, long long n, int& start, int& end) {
+    long long a, e;
+    if (b < XHEAD) { a = b == 0 ? 0 : (long long)XCHAIN << (b - 1); e = (long long)XCHAIN << b; }
+    else { a = (long long)(b - XHEAD + 1) * XSEG; e = a + XSEG; }
+    start = (int)(a < n ? a : n); end = (int)(e < n ? e : n);
+}
 // state: 0 not scannable / done by the walker; 1 guessed: one binade; 2 to fill (one binade); 3 guessed: one crossing at
 // element p (the elements before it in binade ex, pair (e, o); p itself added in hardware; the elements behind it in
 // binade ex + 1, pair (e2, o2)); 4 to fill (crossing)
@@ -528,7 +538,8 @@ __global__ __launch_bounds__(WG) void k_cdfx_summ(const double* __restrict__ w, 
     __shared__ int bad_sh, p_sh;
     if (counters && ld_agent(&counters[1]) == 0) return;
     const int tid = threadIdx.x, b = blockIdx.x + 1;
-    const int start = b * XSEG, end = (int)min((long long)n, (long long)start + XSEG);
+    int start, end;
+    cdfx_range(b, n, start, end);
     const double lo = cdf[start], hi = cdf[end];
     bool ok = lo >= 0x1p-960 && hi < 0x1p1000 && hi >= lo;
     const int ex = ok ? ilogb(lo * (1.0 - XGUESS)) : 0;
@@ -587,45 +598,62 @@ __global__ __launch_bounds__(WG) void k_cdfx_walk(const double* w, int n, double
                                                   const unsigned long long* counters) {
     __shared__ double tile[XCHAIN];
     __shared__ CdfSeg seg_sh[XWALK];
+    __shared__ double s_walk;
+    __shared__ int b_walk;
     if (counters && ld_agent(&counters[1]) == 0) return;
-    const int nseg = (n + XSEG - 1) / XSEG;
+    const int nseg = cdfx_nseg(n);
     if (threadIdx.x == 0) cdf[0] = 0.0;
-    double s = par_seq_range(w, 0, 0.0, min(n, XSEG), cdf, tile);
-    // (the records through LDS, XWALK at a time: one dependent global load per segment was a microsecond each)
-    for (int b = 1; b < nseg; ++b) {
-        if ((b - 1) % XWALK == 0) {
-            __syncthreads();
-            for (int k = threadIdx.x; k < XWALK && b + k < nseg; k += WG) seg_sh[k] = segs[b + k];
-            __syncthreads();
-        }
-        const CdfSeg sg = seg_sh[(b - 1) % XWALK];                   // the same for every thread
-        bool ok = (sg.state == 1 || sg.state == 3) && s >= 0x1p-960 && s < INFINITY && x_exp(s) == sg.ex;
-        double s1 = 0.0, sp = 0.0;
-        if (ok) {
-            const double S0 = s * x_pow2(52 - sg.ex);
-            const double S1 = S0 + (x_odd(S0) ? sg.o : sg.e);
-            ok = S1 < XLIM;                                          // still inside the binade behind the (first) part
-            s1 = S1 * x_pow2(sg.ex - 52);
-        }
-        if (ok && sg.state == 3) {
-            sp = s1 + sg.wp;                                         // the add that crosses, in hardware
-            ok = sp < INFINITY && x_exp(sp) == sg.ex + 1;
-            if (ok) {
-                const double T0 = sp * x_pow2(51 - sg.ex);
-                const double T1 = T0 + (x_odd(T0) ? sg.o2 : sg.e2);
-                ok = T1 < XLIM;
-                s1 = T1 * x_pow2(sg.ex - 51);
+    int start, end;
+    cdfx_range(0, n, start, end);
+    double s = par_seq_range(w, 0, 0.0, end, cdf, tile);
+    int b = 1;
+    // The records go through LDS, XWALK at a time (one dependent global load per segment was a microsecond each), and ONE
+    // wave walks the segments whose guess holds while the others wait at the barrier (sixteen waves in lockstep share the
+    // CU's issue slots: 0.5 us per segment against 0.15); a segment that needs the slow way brings everybody back.
+    while (b < nseg) {
+        __syncthreads();
+        const int b0 = b;
+        for (int k = threadIdx.x; k < XWALK && b0 + k < nseg; k += WG) seg_sh[k] = segs[b0 + k];
+        __syncthreads();
+        if (threadIdx.x < WAVE) {
+            int bb = b0;
+            double ss = s;
+            for (; bb < nseg && bb < b0 + XWALK; ++bb) {
+                const CdfSeg sg = seg_sh[bb - b0];                   // the same for every lane
+                bool ok = (sg.state == 1 || sg.state == 3) && ss >= 0x1p-960 && ss < INFINITY && x_exp(ss) == sg.ex;
+                double s1 = 0.0, sp = 0.0;
+                if (ok) {
+                    const double S0 = ss * x_pow2(52 - sg.ex);
+                    const double S1 = S0 + (x_odd(S0) ? sg.o : sg.e);
+                    ok = S1 < XLIM;                                  // still inside the binade behind the (first) part
+                    s1 = S1 * x_pow2(sg.ex - 52);
+                }
+                if (ok && sg.state == 3) {
+                    sp = s1 + sg.wp;                                 // the add that crosses, in hardware
+                    ok = sp < INFINITY && x_exp(sp) == sg.ex + 1;
+                    if (ok) {
+                        const double T0 = sp * x_pow2(51 - sg.ex);
+                        const double T1 = T0 + (x_odd(T0) ? sg.o2 : sg.e2);
+                        ok = T1 < XLIM;
+                        s1 = T1 * x_pow2(sg.ex - 51);
+                    }
+                }
+                if (!ok) break;
+                if (threadIdx.x == 0) { segs[bb].start = ss; segs[bb].start2 = sp; segs[bb].state = sg.state + 1; }
+                ss = s1;
             }
+            if (threadIdx.x == 0) { s_walk = ss; b_walk = bb; }
         }
-        if (ok) {
-            if (threadIdx.x == 0) { segs[b].start = s; segs[b].start2 = sp; segs[b].state = sg.state + 1; }
-            s = s1;
-        } else {
+        __syncthreads();
+        s = s_walk; b = b_walk;
+        if (b < nseg && b < b0 + XWALK) {                            // (workgroup-uniform) this one the slow way
             if (threadIdx.x == 0) segs[b].state = 0;
 #ifdef CDFX_DEBUG
-            if (threadIdx.x == 0) printf("walker: segment %d of %d the slow way (state %d, ex %d, s %.17g)\n", b, nseg, sg.state, sg.ex, s);
+            if (threadIdx.x == 0) printf("walker: segment %d of %d the slow way (s %.17g)\n", b, nseg, s);
 #endif
-            s = par_seq_range(w, b * XSEG, s, (int)min((long long)n, (long long)(b + 1) * XSEG), cdf, tile);
+            cdfx_range(b, n, start, end);
+            s = par_seq_range(w, start, s, end, cdf, tile);
+            ++b;
         }
     }
 }
@@ -638,7 +666,8 @@ __global__ __launch_bounds__(WG) void k_cdfx_fill(const double* __restrict__ w, 
     if (sg.state != 2 && sg.state != 4) return;                      // workgroup-uniform
     const bool cross = sg.state == 4;
     const int p = cross ? sg.p : INT_MAX;
-    const int start = b * XSEG, end = (int)min((long long)n, (long long)start + XSEG);
+    int start, end;
+    cdfx_range(b, n, start, end);
     const double scaleA = ldexp(1.0, 52 - sg.ex), qA = ldexp(1.0, sg.ex - 52);
     const double scaleB = ldexp(1.0, 51 - sg.ex), qB = ldexp(1.0, sg.ex - 51);
     const int base = start + tid * XE;
@@ -1666,7 +1695,7 @@ hipError_t pfk_resample(hipStream_t st, const double* cdf, const double* u, int 
     } else {
         if (bound > 0.0 && Pg >= PF_MULTI_CDF_MIN && sc.segs) {
             // the sequential-order CDF by many workgroups (each of the three returns at once when no draw was flagged)
-            const int nseg = (Pg + XSEG - 1) / XSEG;
+            const int nseg = cdfx_nseg(Pg);
             CdfSeg* segs = (CdfSeg*)sc.segs;
             hipLaunchKernelGGL(k_cdfx_summ, dim3(nseg - 1), dim3(WG), 0, st, w, Pg, cdf, segs, counters);
             hipLaunchKernelGGL(k_cdfx_walk, dim3(1), dim3(WG), 0, st, w, Pg, (double*)cdf, segs, counters);
@@ -1744,22 +1773,20 @@ hipError_t pfk_resample_prepare(hipStream_t st, const double* w, int Pg, double*
     return hipGetLastError();
 }
 
-size_t pfk_cdf_scratch_bytes(int n) { const size_t nseg = ((size_t)n + XSEG - 1) / XSEG; return (nseg + 1) * sizeof(CdfSeg) + (2 * nseg + 2) * sizeof(double); }
+size_t pfk_cdf_scratch_bytes(int n) { const size_t nw = ((size_t)n + XSEG - 1) / XSEG; return ((size_t)cdfx_nseg(n) + 1) * sizeof(CdfSeg) + (2 * nw + 2) * sizeof(double); }
 hipError_t pfk_cdf_of(hipStream_t st, const double* w, int n, double* cdf, int how, void* scratch) {
     if (how == 2) {                                             // the many-workgroup form (scratch: pfk_cdf_scratch_bytes)
-        const int nseg = (n + XSEG - 1) / XSEG;
+        const int nseg = cdfx_nseg(n), nw = (n + XSEG - 1) / XSEG;
         CdfSeg* segs = (CdfSeg*)scratch;
         double* sums = (double*)(segs + nseg + 1);
-        double* bounds = sums + nseg;
-        if (nseg > 1) {
-            hipLaunchKernelGGL(k_cdfx_segsum, dim3(nseg), dim3(WG), 0, st, w, n, sums);
-            hipLaunchKernelGGL(k_cdfx_bounds, dim3(1), dim3(64), 0, st, sums, nseg, bounds);
-            hipLaunchKernelGGL(k_cdfx_approx, dim3(nseg), dim3(WG), 0, st, w, n, bounds, cdf);
-            hipLaunchKernelGGL(k_cdfx_summ, dim3(nseg - 1), dim3(WG), 0, st, w, n, cdf, segs, (const unsigned long long*)nullptr);
-        }
+        double* bounds = sums + nw;
+        // an approximate CDF first (plain sums), as the weight kernels leave one in the resampler
+        hipLaunchKernelGGL(k_cdfx_segsum, dim3(nw), dim3(WG), 0, st, w, n, sums);
+        hipLaunchKernelGGL(k_cdfx_bounds, dim3(1), dim3(64), 0, st, sums, nw, bounds);
+        hipLaunchKernelGGL(k_cdfx_approx, dim3(nw), dim3(WG), 0, st, w, n, bounds, cdf);
+        hipLaunchKernelGGL(k_cdfx_summ, dim3(nseg - 1), dim3(WG), 0, st, w, n, cdf, segs, (const unsigned long long*)nullptr);
         hipLaunchKernelGGL(k_cdfx_walk, dim3(1), dim3(WG), 0, st, w, n, cdf, segs, (const unsigned long long*)nullptr);
-        if (nseg > 1)
-            hipLaunchKernelGGL(k_cdfx_fill, dim3(nseg - 1), dim3(WG), 0, st, w, n, cdf, segs, (const unsigned long long*)nullptr);
+        hipLaunchKernelGGL(k_cdfx_fill, dim3(nseg - 1), dim3(WG), 0, st, w, n, cdf, segs, (const unsigned long long*)nullptr);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_cdf_of, dim3(1), dim3(WG), 0, st, w, n, cdf, how);

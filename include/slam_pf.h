@@ -389,6 +389,14 @@ int64_t pfh_migration_plan(const int32_t* slot_anc, int64_t n_global, int64_t n_
                            int64_t cap);
 /* S3P:805-812 on the caller's own per-particle records. */
 void pfh_permute(int64_t n, const int32_t* slot_anc, void* records, size_t width);
+/* How pf_set_beams deals K1's column groups to the chunks of its launch (no counterpart in the reference, whose loop
+ * S3P:868-890 walks one list; exported so that the dealing can be checked without a GPU). The groups are sorted by
+ * their number of beams, group_ends[k] = end of the groups with 8 - k beams; the groups of a count go trips[k] to a trip,
+ * the trips of the whole list are numbered through and trip j belongs to chunk j % n_chunks. Out: perm[i] = index in the
+ * sorted list of the group at position i of the chunk-major list (a chunk's groups together, counts descending);
+ * table[9 * y + k] = end of chunk y's groups with 8 - k beams in that list, table[9 * y + 8] = its start. */
+void pfh_deal_groups(const int32_t group_ends[8], int32_t n_chunks, const int32_t trips[8], int32_t* perm,
+                     int32_t* table);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ SYMBOLS = (
     "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init "
     "pf_ring_default_params pf_ring_init pf_ring_paint pf_ring_update pf_ring_state "
     "pf_depth_to_cloud pf_read_occupied pf_sequential_cdf pfh_draw_indices pfh_vote_epilogue pfh_pose_message pfh_migration_plan "
-    "pfh_update_realtime_pos pf_set_best_index pf_scan_vote_static pf_scan_vote_static_warmup").split()
+    "pfh_update_realtime_pos pf_set_best_index pf_scan_vote_static pf_scan_vote_static_warmup pfh_deal_groups").split()
 
 
 class Config(C.Structure):
@@ -520,6 +520,15 @@ def comm_unique_id():
     if rc != 0:
         raise RuntimeError(f"pf_comm_unique_id failed ({rc}): {lib().pf_last_error(None).decode()}")
     return buf.raw
+
+
+def deal_groups(group_ends, n_chunks, trips):
+    """pfh_deal_groups: (perm, table [n_chunks][9]) of K1's chunk-major group list."""
+    ge = _c(group_ends, np.int32); tr = _c(trips, np.int32)
+    assert ge.size == 8 and tr.size == 8
+    perm = np.empty(int(ge[7]), np.int32); table = np.empty((max(int(n_chunks), 1), 9), np.int32)
+    lib().pfh_deal_groups(_p(ge), C.c_int32(n_chunks), _p(tr), _p(perm), _p(table))
+    return perm, table
 
 
 def permute(slot_anc, records):

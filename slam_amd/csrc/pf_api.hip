@@ -115,6 +115,7 @@ struct pf_handle {
     struct TileGroupH { float lx, ly; int32_t n; int32_t lz[PF_TILE_GROUP]; };
     std::vector<TileGroupH> h_tg, h_tg_tmp;
     int tile_ends[PF_TILE_GROUP] = {0};   // ends of the groups with PF_TILE_GROUP, ..., 1 beams in the sorted list
+    std::vector<int32_t> h_deal_perm, h_deal_table;   // pfh_deal_groups' outputs
     int tile_chunks = 1;               // chunks the list in beams_tile was dealt to (its first tile_chunks records are their table)
     int lz_min = 0, lz_max = 0;        // bounds of lz over the occupied beams
     std::vector<unsigned long long> h_sort_keys;
@@ -1173,18 +1174,16 @@ int pf_set_beams(pf_handle* h, const int32_t* bx, const int32_t* by, const int32
         std::vector<pf_handle::TileGroupH>& pg = h->h_tg_tmp;
         pg.clear(); pg.reserve(tg.size());
         h->h_tcols.assign((size_t)C + tg.size(), PfTileG{});
-        for (int y = 0; y < C; ++y) {
-            int32_t* row = (int32_t*)&h->h_tcols[(size_t)y];
-            row[PF_TILE_GROUP] = (int32_t)pg.size();
-            long long slot0 = 0;
-            int g0 = 0;
-            for (int ph = 0; ph < PF_TILE_GROUP; ++ph) {
-                const int g1 = h->tile_ends[ph], T = pfk_tile_trip(PF_TILE_GROUP - ph);
-                const long long nslots = (g1 - g0 + T - 1) / T;
-                for (long long sl = ((y - slot0) % C + C) % C; sl < nslots; sl += C)
-                    for (int g = g0 + (int)sl * T; g < std::min(g0 + ((int)sl + 1) * T, g1); ++g) pg.push_back(tg[(size_t)g]);
-                row[ph] = (int32_t)pg.size();
-                slot0 += nslots; g0 = g1;
+        {
+            int32_t trips[PF_TILE_GROUP];
+            for (int ph = 0; ph < PF_TILE_GROUP; ++ph) trips[ph] = pfk_tile_trip(PF_TILE_GROUP - ph);
+            h->h_deal_perm.resize(tg.size());
+            h->h_deal_table.resize(9 * (size_t)C);
+            pfh_deal_groups(h->tile_ends, C, trips, h->h_deal_perm.data(), h->h_deal_table.data());
+            for (size_t i = 0; i < tg.size(); ++i) pg.push_back(tg[(size_t)h->h_deal_perm[i]]);
+            for (int y = 0; y < C; ++y) {
+                int32_t* row = (int32_t*)&h->h_tcols[(size_t)y];
+                for (int k = 0; k < 9; ++k) row[k] = h->h_deal_table[9 * (size_t)y + (size_t)k];
             }
         }
         h->h_cols.resize(2 * pg.size());

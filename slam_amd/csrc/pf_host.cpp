@@ -181,3 +181,23 @@ void pfh_permute(int64_t n, const int32_t* slot_anc, void* records, size_t width
 }
 
 }  // extern "C"
+
+// K1's column groups dealt to the chunks of its launch (declaration in slam_pf.h).
+extern "C" void pfh_deal_groups(const int32_t group_ends[8], int32_t n_chunks, const int32_t trips[8], int32_t* perm,
+                                int32_t* table) {
+    const int C = n_chunks < 1 ? 1 : n_chunks;
+    int32_t at = 0;
+    for (int y = 0; y < C; ++y) {
+        table[9 * y + 8] = at;
+        long long slot0 = 0;
+        int g0 = 0;
+        for (int ph = 0; ph < 8; ++ph) {
+            const int g1 = group_ends[ph], T = trips[ph] < 1 ? 1 : trips[ph];
+            const long long nslots = (g1 - g0 + T - 1) / T;
+            for (long long sl = ((y - slot0) % C + C) % C; sl < nslots; sl += C)
+                for (int g = g0 + (int)sl * T; g < g0 + ((int)sl + 1) * T && g < g1; ++g) perm[at++] = g;
+            table[9 * y + ph] = at;
+            slot0 += nslots; g0 = g1;
+        }
+    }
+}

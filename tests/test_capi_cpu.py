@@ -272,3 +272,43 @@ def test_migration_plan_moves_every_remote_ancestor(world, P):
             new[r][dst] = tag
     assert all(len(v) == 0 for v in chan.values())
     assert np.array_equal(np.concatenate(new), slot_anc)
+
+
+def test_deal_groups_gives_every_group_to_exactly_one_chunk():
+    """pfh_deal_groups, the host logic behind K1's chunk-major group list (pf_set_beams): the list it lays out is a
+    permutation of the sorted one, every chunk's share is contiguous and ordered by count, the table's ends fit, the trips
+    of a count are dealt round-robin through the counts (shares differ by at most one trip per count and over the whole
+    list), and a short last trip stays in one chunk."""
+    rng = np.random.default_rng(4)
+    cases = [([0] * 8, 1, [1] * 8), ([5] * 8, 3, [2] * 8), ([0, 0, 0, 0, 0, 0, 0, 7], 51, [1, 1, 1, 1, 2, 2, 2, 2])]
+    for _ in range(60):
+        counts = rng.integers(0, 200, 8) * (rng.random(8) < 0.8)
+        cases.append((np.cumsum(counts).tolist(), int(rng.integers(1, 70)), rng.integers(1, 5, 8).tolist()))
+    for ends, C_, trips in cases:
+        perm, table = capi.deal_groups(ends, C_, trips)
+        n = ends[7]
+        assert sorted(perm.tolist()) == list(range(n))
+        count_of = np.zeros(n, np.int64)                      # phase (0: eight beams ... 7: one) of every sorted group
+        g0 = 0
+        for ph in range(8):
+            count_of[g0:ends[ph]] = ph; g0 = ends[ph]
+        at = 0
+        trips_of = np.zeros((C_, 8), np.int64)
+        for y in range(C_):
+            assert table[y, 8] == at
+            for ph in range(8):
+                seg = perm[at:table[y, ph]]
+                assert np.all(count_of[seg] == ph)
+                assert np.all(np.diff(seg) > 0)               # list order kept inside a chunk's count
+                T = trips[ph]
+                first = ends[ph - 1] if ph else 0
+                # whole trips: a chunk's groups of a count come in runs of T consecutive sorted groups from a trip boundary
+                for k in range(0, len(seg), T):
+                    run = seg[k:k + T]
+                    assert (run[0] - first) % T == 0 and np.all(np.diff(run) == 1)
+                    assert len(run) == T or run[-1] == ends[ph] - 1
+                trips_of[y, ph] = (len(seg) + T - 1) // T
+                at = int(table[y, ph])
+        assert at == n
+        assert np.all(trips_of.max(0) - trips_of.min(0) <= 1)
+        assert trips_of.sum(1).max() - trips_of.sum(1).min() <= 1

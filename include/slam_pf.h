@@ -286,6 +286,37 @@ int pf_ring_state(pf_handle* h, int32_t* counts, int32_t* lives, double pos_upda
 int pf_depth_to_cloud(pf_handle* h, const uint8_t* image, int32_t width, int32_t height, int32_t pool,
                       double focal, double* cloud_out, int64_t capacity, int64_t* n_out);
 
+/* ---- the cloud kept on the GPU between the stages of callback(): S3P:126, 168-205 --------------
+ * The reference's cloudpoints (S3P:126) is one member array that img_to_cloud() fills and
+ * scan_localization(), scan_localization_map_update() and build_local_map() read (S3P:320-322,
+ * 439-440, 628-631). These four calls are the same stages with that array in HBM: cloud_dev is the
+ * CALLER's device buffer, double [capacity][3] on the handle's GPU, so no point crosses PCIe: what
+ * comes back per frame is the point count (the caller draws its indices from it, S3P:317, 666), the
+ * vote's sums and the ring's in-bounds count. Results are those of the host forms bit for bit
+ * (tests/test_gpu_frontend.py). Each call reads or writes cloud_dev on its handle's stream: handles on
+ * different streams (the localisation grid's and the local map's, say) are ordered by the caller,
+ * most simply by pf_set_stream(mapper, pf_stream(loc)). The host forms reject a coordinate that is
+ * not finite or not below 1e6 in magnitude; here nobody on the host sees the points, so such a
+ * coordinate makes its point contribute nothing (no vote, no ring entry, no hit, no ray) -- clouds
+ * from pf_depth_to_cloud_device (uint16 millimetres) never hold one.
+ *
+ * S3P:562-612 as pf_depth_to_cloud, the cloud left in cloud_dev; *n_out = its rows. */
+int pf_depth_to_cloud_device(pf_handle* h, const uint8_t* image, int32_t width, int32_t height, int32_t pool,
+                             double focal, double* cloud_dev, int64_t capacity, int64_t* n_out);
+/* S3P:315-376 as pf_scan_vote with the points the rows pick[0..n_points) of cloud_dev (S3P:320-322:
+ * points_scan[i] = cloudpoints[rand_idx]); pick: host, every entry in [0, n_cloud). */
+int pf_scan_vote_device(pf_handle* h, const double* cloud_dev, int64_t n_cloud, const int32_t* pick,
+                        int64_t n_points, const double pos[3], const double zyx[3], int32_t n_yaw,
+                        int32_t yaw_k0, int32_t yaw_kstep, int32_t n_t, double length, int32_t* sums_out,
+                        int64_t* best_out);
+/* S3P:419-529 as pf_ring_update, the cloud read where it is. */
+int pf_ring_update_device(pf_handle* h, const double* cloud_dev, int64_t n_points, double pos_scan[3],
+                          const double zyx[3], int32_t* flags_out);
+/* S3P:628-631, 668-672 as pf_set_scan: the handle takes its own copy of the rows (device to device, on
+ * its stream), so cloud_dev may be rewritten once that copy has run; ray_idx: host. */
+int pf_set_scan_device(pf_handle* h, const double* cloud_dev, int64_t n_points, const int32_t* ray_idx,
+                       int64_t n_rays);
+
 /* ---- map read-out for publishing: S3P:1031-1051 with reverse_index_conv_p S3P:100-110 ---------
  *  Every stride-th cell (S3P:1031: 4) of a grid (slab `particle` of the local
  * shard, ignored on a PF_MAP_SHARED handle, like pf_read_map) above threshold (S3P:1033: 80), in index

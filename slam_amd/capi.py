@@ -29,7 +29,8 @@ SYMBOLS = (
     "pfh_permute pfh_vote_hypothesis pf_comm_unique_id pf_comm_init "
     "pf_ring_default_params pf_ring_init pf_ring_paint pf_ring_update pf_ring_state "
     "pf_depth_to_cloud pf_read_occupied pf_sequential_cdf pfh_draw_indices pfh_vote_epilogue pfh_pose_message pfh_migration_plan "
-    "pfh_update_realtime_pos pf_set_best_index pf_scan_vote_static pf_scan_vote_static_warmup pfh_deal_groups").split()
+    "pfh_update_realtime_pos pf_set_best_index pf_scan_vote_static pf_scan_vote_static_warmup pfh_deal_groups "
+    "pf_depth_to_cloud_device pf_scan_vote_device pf_ring_update_device pf_set_scan_device").split()
 
 
 class Config(C.Structure):
@@ -340,6 +341,41 @@ class Handle:
                                          C.c_double(focal), _p(out), C.c_int64(cap), C.byref(n)),
                  "pf_depth_to_cloud")
         return out[:n.value].copy()
+
+    # --- the same stages with the cloud kept in HBM (S3P:126): cloud_ptr is the caller's device buffer (an int) ---
+    def depth_to_cloud_device(self, image, width, height, cloud_ptr, capacity, pool=4, focal=385.0 / 4.0):
+        """Returns the number of rows written to the device buffer."""
+        image = _c(np.frombuffer(image, np.uint8) if isinstance(image, (bytes, bytearray)) else image, np.uint8)
+        if image.size != width * height * 2:
+            raise PfError("image must hold width*height*2 bytes")
+        n = C.c_int64(0)
+        self._ck(lib().pf_depth_to_cloud_device(self._h, _p(image), C.c_int32(width), C.c_int32(height), C.c_int32(pool),
+                                                C.c_double(focal), C.c_void_p(cloud_ptr), C.c_int64(capacity), C.byref(n)),
+                 "pf_depth_to_cloud_device")
+        return n.value
+
+    def scan_vote_device(self, cloud_ptr, n_cloud, pick, pos, zyx, n_yaw=5, yaw_k0=-6, yaw_kstep=3, n_t=5, length=0.25):
+        pick = _c(pick, np.int32)
+        pos = _c(pos, np.float64); zyx = _c(zyx, np.float64)
+        sums = np.empty(n_yaw * n_t ** 3, np.int32)
+        best = C.c_int64(-1)
+        self._ck(lib().pf_scan_vote_device(self._h, C.c_void_p(cloud_ptr), C.c_int64(n_cloud), _p(pick),
+                                           C.c_int64(len(pick)), _p(pos), _p(zyx), n_yaw, yaw_k0, yaw_kstep, n_t,
+                                           C.c_double(length), _p(sums), C.byref(best)), "pf_scan_vote_device")
+        return sums, best.value
+
+    def ring_update_device(self, cloud_ptr, n_points, pos_scan, zyx):
+        """Returns (flags, pos_scan after the call)."""
+        pos = np.array(pos_scan, np.float64); zyx = _c(zyx, np.float64)
+        flags = C.c_int32(0)
+        self._ck(lib().pf_ring_update_device(self._h, C.c_void_p(cloud_ptr), C.c_int64(n_points), _p(pos), _p(zyx),
+                                             C.byref(flags)), "pf_ring_update_device")
+        return flags.value, pos
+
+    def set_scan_device(self, cloud_ptr, n_points, ray_idx):
+        ray_idx = _c(ray_idx, np.int32)
+        self._ck(lib().pf_set_scan_device(self._h, C.c_void_p(cloud_ptr), C.c_int64(n_points), _p(ray_idx),
+                                          C.c_int64(len(ray_idx))), "pf_set_scan_device")
 
     def read_occupied(self, particle=0, threshold=80, stride=4, capacity=None):
         """Returns (float32 [n][3], total qualifying cells)."""

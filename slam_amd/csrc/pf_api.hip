@@ -203,6 +203,8 @@ struct pf_handle {
                                        // (pf_resample's fill stage counted them)
     double* points = nullptr;          // [max_points][3]
     double* wpts = nullptr;            // [max_points][3]
+    // the local map's ray march as count + apply (PfUpdateWork::cnt), allocated by the first pf_update_map on it
+    unsigned* ray_cnt = nullptr;       // [local_elements + 3], zero between calls
     int32_t* ray_idx = nullptr;        // [max_points]
     bool full_list_resident = true, occ_lists_resident = true;   // false: still in h_beams / h_beams_occ(_f) only
     std::vector<double> h_ysum;        // pf_predict's per-chunk yaw sums and first bad indices
@@ -619,7 +621,7 @@ void pf_destroy(pf_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->ring_idx, h->ring_cnt, h->ring_pts, h->vote_scratch, h->bmin, h->bmin_ext, h->bmin_all, h->shadow, h->sorted, h->pose, h->w, h->logw, h->cdf, h->scratch, h->u, h->maps, h->local, h->beam_blk,
                     h->partial, h->scores, h->draw, h->first, h->dup_anc, h->free_slot,
-                    h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_ext, h->order_hist[0], h->order_hist[1], h->points, h->wpts};
+                    h->slot_anc, h->counters, h->rs_mem, h->vox, h->order, h->order_keys, h->order_ext, h->order_hist[0], h->order_hist[1], h->points, h->wpts, h->ray_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& v : h->ev) for (auto& e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1667,6 +1669,36 @@ int pf_set_scan(pf_handle* h, const double* points, int64_t n_points, const int3
     return PF_OK;
 }
 
+int pf_set_scan_device(pf_handle* h, const double* cloud_dev, int64_t n_points, const int32_t* ray_idx,
+                       int64_t n_rays) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, n_points >= 0 && n_points <= h->cfg.max_points, "n_points beyond max_points");
+    NEED(h, n_rays >= 0 && n_rays <= h->cfg.max_points, "n_rays beyond max_points");
+    NEED(h, (n_points == 0 || cloud_dev) && (n_rays == 0 || ray_idx), "null array");
+    {
+        bool ok = true;
+        for (int64_t r = 0; r < n_rays; ++r) ok &= (uint64_t)(int64_t)ray_idx[r] < (uint64_t)n_points;
+        if (!ok)
+            for (int64_t r = 0; r < n_rays; ++r)
+                if (ray_idx[r] < 0 || ray_idx[r] >= n_points)
+                    return fail(h, PF_ERR_ARG, "pf_set_scan_device: ray_idx[%lld] outside [0, n_points)", (long long)r);
+    }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, wait_map_writes(h));
+    const size_t nb_p = sizeof(double) * 3 * (size_t)n_points, nb_r = sizeof(int32_t) * (size_t)n_rays;
+    const size_t off_r = up256(nb_p);                  // the same place as in pf_set_scan
+    h->ray_idx = (int32_t*)((char*)h->points + off_r);
+    HIP_TRY(h, pfk_copy_points(h->stream, cloud_dev, (int)n_points, h->points));
+    if (n_rays) {
+        char* slot = nullptr;
+        HIP_TRY(h, h->st_scan.acquire(nb_r + 8, &slot));
+        memcpy(slot, ray_idx, nb_r);
+        HIP_TRY(h, hipMemcpyAsync(h->ray_idx, slot, nb_r, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, h->st_scan.commit(h->stream));
+    }
+    h->n_points = (int)n_points; h->n_rays = (int)n_rays;
+    return PF_OK;
+}
 int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const double pos[3],
                   const double zyx[3]) {
     if (!h) return PF_ERR_ARG;
@@ -1710,6 +1742,15 @@ int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const dou
         h->upd_pending = true;
         return PF_OK;
     }
+    // SLAM_PF_COUNT=0: the march by compare-and-swap per step (comparison)
+    static const bool count_wanted = !(getenv("SLAM_PF_COUNT") && atoi(getenv("SLAM_PF_COUNT")) == 0);
+    if (count_wanted && h->n_rays > 0) {
+        if (!h->ray_cnt) {
+            HIP_TRY(h, dalloc(&h->ray_cnt, (size_t)h->local_elements + 3));
+            HIP_TRY(h, hipMemsetAsync(h->ray_cnt, 0, sizeof(unsigned) * ((size_t)h->local_elements + 3), h->stream));
+        }
+        uw.cnt = h->ray_cnt;
+    }
     Timed t(h, PF_K_UPDATE);
     HIP_TRY(h, pfk_update_hits(h->stream, uw));
     HIP_TRY(h, pfk_update_rays(h->stream, uw));
@@ -1717,16 +1758,11 @@ int pf_update_map(pf_handle* h, int target, const pf_update_params* p, const dou
 }
 
 static int grow_scratch(pf_handle* h, size_t need);
-int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const double pos[3],
-                 const double zyx[3], int32_t n_yaw, int32_t yaw_k0, int32_t yaw_kstep,
-                 int32_t n_t, double length, int32_t* sums_out, int64_t* best_out) {
-    if (!h) return PF_ERR_ARG;
-    NEED(h, h->cfg.map_mode == PF_MAP_SHARED, "needs a PF_MAP_SHARED handle (the grid voted on)");
-    NEED(h, pos && zyx && best_out, "null argument");
-    NEED(h, n_points >= 0 && n_points <= h->cfg.max_points && (n_points == 0 || points), "n_points beyond max_points");
-    NEED(h, n_yaw >= 1 && n_yaw <= 64 && n_t >= 1 && n_t <= 16, "lattice size");
-    for (int64_t i = 0; i < 3 * n_points; ++i)
-        if (!(fabs(points[i]) < 1.0e6)) return fail(h, PF_ERR_ARG, "pf_scan_vote: point %lld not finite/too far", (long long)(i / 3));
+// S3P:315-376. points: host rows (cloud_dev == nullptr), or cloud_dev: device rows of which the vote takes
+// the n_points rows pick[] names (S3P:320-322 done by the rotation kernel's loads).
+static int scan_vote(pf_handle* h, const double* points, const double* cloud_dev, const int32_t* pick,
+                     int64_t n_points, const double pos[3], const double zyx[3], int32_t n_yaw, int32_t yaw_k0,
+                     int32_t yaw_kstep, int32_t n_t, double length, int32_t* sums_out, int64_t* best_out) {
     const double pi = 2 * acos(0.0);                              // S3P:24
     const double res = h->cfg.resolution;
     const int per = n_t * n_t * n_t, nh = n_yaw * per;
@@ -1752,7 +1788,8 @@ int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const dou
     const size_t nb_s = up256(sizeof(int32_t) * (size_t)nh);
     // the sampled points are staged here too, not in the scan buffers of pf_set_scan: a later
     // pf_update_map on this handle still marches over the scan it was given
-    const size_t nb_p = sizeof(double) * 3 * (size_t)(n_points ? n_points : 1);
+    const size_t nb_p = cloud_dev ? up256(sizeof(int32_t) * (size_t)(n_points ? n_points : 1))
+                                  : sizeof(double) * 3 * (size_t)(n_points ? n_points : 1);
     if (int rc = grow_scratch(h, nb_m + nb_t + nb_r + nb_s + nb_p + 64)) return rc;
     char* dev = h->vote_scratch;
     double* d_m = (double*)dev; double* d_t = (double*)(dev + nb_m);
@@ -1762,11 +1799,12 @@ int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const dou
     hipError_t e = hipMemcpyAsync(d_m, mats.data(), nb_m, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_t, trans.data(), nb_t, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess && n_points)
-        e = hipMemcpyAsync(d_p, points, sizeof(double) * 3 * (size_t)n_points, hipMemcpyHostToDevice, h->stream);
+        e = cloud_dev ? hipMemcpyAsync(d_p, pick, sizeof(int32_t) * (size_t)n_points, hipMemcpyHostToDevice, h->stream)
+                      : hipMemcpyAsync(d_p, points, sizeof(double) * 3 * (size_t)n_points, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         Timed t(h, PF_K_VOTE);
-        e = pfk_scan_vote(h->stream, h->maps, d_p, (int)n_points, d_m, n_yaw, d_t, per, 1 / res,
-                          h->cfg.grid_y, h->cfg.grid_z, h->elements, d_r, d_s);
+        e = pfk_scan_vote(h->stream, h->maps, cloud_dev ? cloud_dev : d_p, cloud_dev ? (const int32_t*)d_p : nullptr,
+                          (int)n_points, d_m, n_yaw, d_t, per, 1 / res, h->cfg.grid_y, h->cfg.grid_z, h->elements, d_r, d_s);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(sums.data(), d_s, sizeof(int32_t) * (size_t)nh, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1791,6 +1829,36 @@ static int grow_scratch(pf_handle* h, size_t need) {
     return PF_OK;
 }
 
+
+int pf_scan_vote(pf_handle* h, const double* points, int64_t n_points, const double pos[3],
+                 const double zyx[3], int32_t n_yaw, int32_t yaw_k0, int32_t yaw_kstep,
+                 int32_t n_t, double length, int32_t* sums_out, int64_t* best_out) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, h->cfg.map_mode == PF_MAP_SHARED, "needs a PF_MAP_SHARED handle (the grid voted on)");
+    NEED(h, pos && zyx && best_out, "null argument");
+    NEED(h, n_points >= 0 && n_points <= h->cfg.max_points && (n_points == 0 || points), "n_points beyond max_points");
+    NEED(h, n_yaw >= 1 && n_yaw <= 64 && n_t >= 1 && n_t <= 16, "lattice size");
+    for (int64_t i = 0; i < 3 * n_points; ++i)
+        if (!(fabs(points[i]) < 1.0e6)) return fail(h, PF_ERR_ARG, "pf_scan_vote: point %lld not finite/too far", (long long)(i / 3));
+    return scan_vote(h, points, nullptr, nullptr, n_points, pos, zyx, n_yaw, yaw_k0, yaw_kstep, n_t, length, sums_out, best_out);
+}
+
+int pf_scan_vote_device(pf_handle* h, const double* cloud_dev, int64_t n_cloud, const int32_t* pick, int64_t n_points,
+                        const double pos[3], const double zyx[3], int32_t n_yaw, int32_t yaw_k0, int32_t yaw_kstep,
+                        int32_t n_t, double length, int32_t* sums_out, int64_t* best_out) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, h->cfg.map_mode == PF_MAP_SHARED, "needs a PF_MAP_SHARED handle (the grid voted on)");
+    NEED(h, pos && zyx && best_out, "null argument");
+    NEED(h, n_cloud >= 0 && n_cloud < (1ll << 31) && (n_cloud == 0 || cloud_dev), "n_cloud");
+    NEED(h, n_points >= 0 && n_points <= h->cfg.max_points && (n_points == 0 || pick), "n_points beyond max_points");
+    NEED(h, n_yaw >= 1 && n_yaw <= 64 && n_t >= 1 && n_t <= 16, "lattice size");
+    for (int64_t i = 0; i < n_points; ++i)
+        if (pick[i] < 0 || pick[i] >= n_cloud)
+            return fail(h, PF_ERR_ARG, "pf_scan_vote_device: pick[%lld] outside [0, n_cloud)", (long long)i);
+    return scan_vote(h, nullptr, n_points ? cloud_dev : nullptr, pick, n_points, pos, zyx, n_yaw, yaw_k0, yaw_kstep, n_t,
+                     length, sums_out, best_out);
+}
+
 int pf_sequential_cdf(pf_handle* h, const double* w, int64_t n, int32_t how, double* cdf_out) {
     if (!h) return PF_ERR_ARG;
     NEED(h, w && cdf_out && n >= 1 && n <= (int64_t)1 << 30, "null argument / n outside 1..2^30");
@@ -1809,31 +1877,54 @@ int pf_sequential_cdf(pf_handle* h, const double* w, int64_t n, int32_t how, dou
     return PF_OK;
 }
 
+// S3P:562-612. cloud_dev == nullptr: the cloud lands in the handle's scratch (*cloud_at says where);
+// the count is the one value that comes back to the host here.
+static int depth_cloud(pf_handle* h, const char* who, const uint8_t* image, int32_t width, int32_t height, int32_t pool,
+                       double focal, double* cloud_dev, int64_t capacity, double** cloud_at, int32_t* n_out) {
+    if (!(pool >= 1 && pool <= 16 && width >= pool && height >= pool && width <= 16384 && height <= 16384))
+        return fail(h, PF_ERR_ARG, "%s: image size / pool factor", who);
+    if (!(focal > 0 && focal < 1.0e9)) return fail(h, PF_ERR_ARG, "%s: focal length", who);
+    const int64_t npix = (int64_t)(width / pool) * (height / pool);
+    if (capacity < npix) return fail(h, PF_ERR_ARG, "%s: the cloud holds fewer than (width/pool)*(height/pool) points", who);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t nb_i = up256((size_t)width * height * 2), nb_d = up256(sizeof(int4) * (size_t)npix);
+    const size_t nb_c = cloud_dev ? 0 : up256(sizeof(double) * 3 * (size_t)npix);
+    const size_t nb_b = up256(sizeof(int32_t) * (size_t)((npix + 255) / 256));
+    if (int rc = grow_scratch(h, nb_i + nb_d + nb_c + 256 + nb_b)) return rc;
+    char* dev = h->vote_scratch;
+    uint8_t* d_img = (uint8_t*)dev; int4* d_pix = (int4*)(dev + nb_i);
+    double* d_cloud = cloud_dev ? cloud_dev : (double*)(dev + nb_i + nb_d);
+    int32_t* d_n = (int32_t*)(dev + nb_i + nb_d + nb_c);
+    int32_t* d_b = (int32_t*)(dev + nb_i + nb_d + nb_c + 256);
+    int32_t n = 0;
+    HIP_TRY(h, hipMemcpyAsync(d_img, image, (size_t)width * height * 2, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, pfk_depth_to_cloud(h->stream, d_img, width, height, pool, focal, d_pix, d_cloud, d_n, d_b));
+    HIP_TRY(h, hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *cloud_at = d_cloud; *n_out = n;
+    return PF_OK;
+}
+
 int pf_depth_to_cloud(pf_handle* h, const uint8_t* image, int32_t width, int32_t height, int32_t pool,
                       double focal, double* cloud_out, int64_t capacity, int64_t* n_out) {
     if (!h) return PF_ERR_ARG;
     NEED(h, image && cloud_out && n_out, "null argument");
-    NEED(h, pool >= 1 && pool <= 16 && width >= pool && height >= pool && width <= 16384 && height <= 16384,
-         "image size / pool factor");
-    NEED(h, focal > 0 && focal < 1.0e9, "focal length");
-    const int64_t npix = (int64_t)(width / pool) * (height / pool);
-    NEED(h, capacity >= npix, "cloud_out holds fewer than (width/pool)*(height/pool) points");
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
-    const size_t nb_i = up256((size_t)width * height * 2), nb_d = up256(sizeof(int4) * (size_t)npix);
-    const size_t nb_c = up256(sizeof(double) * 3 * (size_t)npix);
-    if (int rc = grow_scratch(h, nb_i + nb_d + nb_c + 256)) return rc;
-    char* dev = h->vote_scratch;
-    uint8_t* d_img = (uint8_t*)dev; int4* d_pix = (int4*)(dev + nb_i);
-    double* d_cloud = (double*)(dev + nb_i + nb_d); int32_t* d_n = (int32_t*)(dev + nb_i + nb_d + nb_c);
-    int32_t n = 0;
-    HIP_TRY(h, hipMemcpyAsync(d_img, image, (size_t)width * height * 2, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, pfk_depth_to_cloud(h->stream, d_img, width, height, pool, focal, d_pix, d_cloud, d_n));
-    HIP_TRY(h, hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    double* d_cloud = nullptr; int32_t n = 0;
+    if (int rc = depth_cloud(h, "pf_depth_to_cloud", image, width, height, pool, focal, nullptr, capacity, &d_cloud, &n)) return rc;
     if (n > 0) {
         HIP_TRY(h, hipMemcpyAsync(cloud_out, d_cloud, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
+    *n_out = n;
+    return PF_OK;
+}
+
+int pf_depth_to_cloud_device(pf_handle* h, const uint8_t* image, int32_t width, int32_t height, int32_t pool,
+                             double focal, double* cloud_dev, int64_t capacity, int64_t* n_out) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, image && cloud_dev && n_out, "null argument");
+    double* at = nullptr; int32_t n = 0;
+    if (int rc = depth_cloud(h, "pf_depth_to_cloud_device", image, width, height, pool, focal, cloud_dev, capacity, &at, &n)) return rc;
     *n_out = n;
     return PF_OK;
 }
@@ -1936,24 +2027,20 @@ int pf_ring_paint(pf_handle* h) {
     NEED(h, h->ring_idx, "pf_ring_init first");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, wait_map_writes(h));
+    PfRingPaint rp{};
+    rp.cap = h->ring.slot_capacity;
     for (int i = 0; i < h->ring.n_slots; ++i)                                     // S3P:305-312
-        if (h->ring_life[(size_t)i] > 0)
-            HIP_TRY(h, pfk_ring_set(h->stream, h->maps, h->ring_idx + (size_t)i * h->ring.slot_capacity,
-                                    h->ring_count[(size_t)i], 1));
+        if (h->ring_life[(size_t)i] > 0 && h->ring_count[(size_t)i] > 0) {
+            rp.slot[rp.n] = i; rp.count[rp.n] = h->ring_count[(size_t)i]; ++rp.n;
+        }
+    HIP_TRY(h, pfk_ring_paint(h->stream, h->maps, h->ring_idx, rp));
     h->shadow_dirty = true;
     return PF_OK;
 }
 
-int pf_ring_update(pf_handle* h, const double* cloud, int64_t n_points, double pos_scan[3],
-                   const double zyx[3], int32_t* flags_out) {
-    if (!h) return PF_ERR_ARG;
-    NEED(h, h->ring_idx, "pf_ring_init first");
-    NEED(h, pos_scan && zyx && (n_points == 0 || cloud), "null argument");
-    NEED(h, n_points >= 0 && n_points <= h->ring.slot_capacity, "n_points beyond slot_capacity");
-    for (int k = 0; k < 3; ++k)
-        NEED(h, isfinite(pos_scan[k]) && fabs(pos_scan[k]) < 1e6 && isfinite(zyx[k]), "pose not finite");
-    for (int64_t i = 0; i < 3 * n_points; ++i)
-        if (!(fabs(cloud[i]) < 1.0e6)) return fail(h, PF_ERR_ARG, "pf_ring_update: point %lld not finite/too far", (long long)(i / 3));
+// S3P:419-529. cloud: host rows, or (on_device) device rows read where they are.
+static int ring_update(pf_handle* h, const double* cloud, bool on_device, int64_t n_points, double pos_scan[3],
+                       const double zyx[3], int32_t* flags_out) {
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, wait_map_writes(h));
     const pf_ring_params& rp = h->ring;
@@ -1980,10 +2067,11 @@ int pf_ring_update(pf_handle* h, const double* cloud, int64_t n_points, double p
                 up.conv = conv; up.elements = h->elements; up.gy = h->cfg.grid_y; up.gz = h->cfg.grid_z;
                 int32_t cnt = 0;
                 if (n_points) {
-                    HIP_TRY(h, hipMemcpyAsync(h->ring_pts, cloud, sizeof(double) * 3 * (size_t)n_points,
-                                              hipMemcpyHostToDevice, h->stream));
+                    if (!on_device)
+                        HIP_TRY(h, hipMemcpyAsync(h->ring_pts, cloud, sizeof(double) * 3 * (size_t)n_points,
+                                                  hipMemcpyHostToDevice, h->stream));
                     HIP_TRY(h, hipMemsetAsync(h->ring_cnt, 0, sizeof(int32_t), h->stream));
-                    HIP_TRY(h, pfk_ring_fill(h->stream, h->ring_pts, (int)n_points, up, slot, h->ring_cnt));
+                    HIP_TRY(h, pfk_ring_fill(h->stream, on_device ? cloud : h->ring_pts, (int)n_points, up, slot, h->ring_cnt));
                     HIP_TRY(h, hipMemcpyAsync(&cnt, h->ring_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
                     HIP_TRY(h, hipStreamSynchronize(h->stream));
                 }
@@ -2024,6 +2112,30 @@ int pf_ring_update(pf_handle* h, const double* cloud, int64_t n_points, double p
     }
     if (flags_out) *flags_out = flags;
     return PF_OK;
+}
+
+int pf_ring_update(pf_handle* h, const double* cloud, int64_t n_points, double pos_scan[3],
+                   const double zyx[3], int32_t* flags_out) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, h->ring_idx, "pf_ring_init first");
+    NEED(h, pos_scan && zyx && (n_points == 0 || cloud), "null argument");
+    NEED(h, n_points >= 0 && n_points <= h->ring.slot_capacity, "n_points beyond slot_capacity");
+    for (int k = 0; k < 3; ++k)
+        NEED(h, isfinite(pos_scan[k]) && fabs(pos_scan[k]) < 1e6 && isfinite(zyx[k]), "pose not finite");
+    for (int64_t i = 0; i < 3 * n_points; ++i)
+        if (!(fabs(cloud[i]) < 1.0e6)) return fail(h, PF_ERR_ARG, "pf_ring_update: point %lld not finite/too far", (long long)(i / 3));
+    return ring_update(h, cloud, false, n_points, pos_scan, zyx, flags_out);
+}
+
+int pf_ring_update_device(pf_handle* h, const double* cloud_dev, int64_t n_points, double pos_scan[3],
+                          const double zyx[3], int32_t* flags_out) {
+    if (!h) return PF_ERR_ARG;
+    NEED(h, h->ring_idx, "pf_ring_init first");
+    NEED(h, pos_scan && zyx && (n_points == 0 || cloud_dev), "null argument");
+    NEED(h, n_points >= 0 && n_points <= h->ring.slot_capacity, "n_points beyond slot_capacity");
+    for (int k = 0; k < 3; ++k)
+        NEED(h, isfinite(pos_scan[k]) && fabs(pos_scan[k]) < 1e6 && isfinite(zyx[k]), "pose not finite");
+    return ring_update(h, cloud_dev, true, n_points, pos_scan, zyx, flags_out);
 }
 
 int pf_ring_state(pf_handle* h, int32_t* counts, int32_t* lives, double pos_update[3],

@@ -302,6 +302,10 @@ struct PfUpdateWork {
     PfUpdateParams up;
     int near_steps;         // > 0: the rays' first near_steps steps are counted per cell in LDS by d5_rays_near's workgroups
                             // and d5_rays starts behind them; 0: d5_rays marches every step
+    // pfk_update_rays' counting form (cnt != null; a grid of its own, no gather-layout copy): the march only COUNTS
+    // its touches per cell, a second launch applies count * miss_inc with one clamp per counted cell
+    unsigned* cnt;          // [elements rounded up to 4], 16-byte aligned, all zero between calls
+    int near_wgs;
 };
 // Every ray starts at the sensor: its first steps land in the same few hundred cells as every other ray's, and a
 // compare-and-swap per touch on those words serialises (2400 rays on the reference's empty local map: 217 us of
@@ -321,14 +325,17 @@ hipError_t pfk_update_rays(hipStream_t st, const PfUpdateWork& uw);
 hipError_t pfk_fill_u8(hipStream_t st, uint8_t* dst, unsigned long long n, int value);
 
 // K6: S3P:328-376. mats: double [n_yaw][9]; trans: double [n_yaw*n_per_yaw][3]; rot: scratch
-// double [n_yaw][N][3]; sums: int32 [n_yaw*n_per_yaw].
-hipError_t pfk_scan_vote(hipStream_t st, const uint8_t* grid, const double* points, int N,
+// double [n_yaw][N][3]; sums: int32 [n_yaw*n_per_yaw]. pick (may be null): the N rows of points voted with.
+hipError_t pfk_scan_vote(hipStream_t st, const uint8_t* grid, const double* points, const int32_t* pick, int N,
                          const double* mats, int n_yaw, const double* trans, int n_per_yaw,
                          double conv, int gy, int gz, long long elements, double* rot,
                          int32_t* sums);
 
 // Keyframe ring (S3P:305-312, 419-529). slot: int32 [cap] flat indices of one ring slot.
 hipError_t pfk_ring_set(hipStream_t st, uint8_t* grid, const int32_t* slot, int count, int value);
+// the live slots of a ring int32 [n_slots][cap] painted with 1 in one launch: slot[k], count[k] for k < n <= 64
+struct PfRingPaint { int32_t n, cap; int32_t slot[64]; int32_t count[64]; };
+hipError_t pfk_ring_paint(hipStream_t st, uint8_t* grid, const int32_t* ring, const PfRingPaint& rp);
 // *count_out (zero on entry) += in-bounds points; up: rot, pos, conv, gy, gz, elements.
 hipError_t pfk_ring_fill(hipStream_t st, const double* points, int n, PfUpdateParams up, int32_t* slot,
                          int32_t* count_out);
@@ -336,9 +343,12 @@ hipError_t pfk_ring_shift(hipStream_t st, int32_t* slot, int count, long long co
                           int32_t* count_out);
 
 // Depth front-end (S3P:562-612). image: device copy of the uint16 little-endian depth bytes;
-// dpix: int4 [npix] scratch; cloud: double [npix][3]; *count_out = points written.
+// dpix: int4 [npix] scratch; cloud: double [npix][3]; *count_out = points written; bcnt (may be null): int32
+// [ceil(npix/256)] scratch for the many-workgroup compaction (images of up to 262 144 pooled pixels).
 hipError_t pfk_depth_to_cloud(hipStream_t st, const uint8_t* image, int width, int height, int pool,
-                              double focal, int4* dpix, double* cloud, int32_t* count_out);
+                              double focal, int4* dpix, double* cloud, int32_t* count_out, int32_t* bcnt);
+// dst[k] = src[k] for the 3n coordinates of n points, NaN where |src[k]| < 1e6 does not hold (pf_set_scan_device).
+hipError_t pfk_copy_points(hipStream_t st, const double* src, int n, double* dst);
 // Map read-out (S3P:1031-1051). bcnt: int32 [nb], nb = ceil(ceil(elements/stride)/1024);
 // *total_out = qualifying cells (may exceed cap; only the first cap are written).
 hipError_t pfk_read_occupied(hipStream_t st, const uint8_t* map, long long elements, int stride,

@@ -986,6 +986,129 @@ __global__ __launch_bounds__(256) void k_update_rays_near(PfUpdateWork uw) {
     d5_rays((blockIdx.x - PF_NEAR_WGS) * PF_RAYS_PER_WG + threadIdx.x / PF_RAY_LANES, threadIdx.x % PF_RAY_LANES, uw);
 }
 
+// ---- the ray march as count + apply (PfUpdateWork::cnt) ----------------------------------------------------
+// A miss is v -> max(v + inc, clamp) whichever ray brings it, so k misses of a cell are one touch of k * inc
+// (d5_rays_near uses the same fact for the first steps). Here EVERY step only adds to its cell's counter: an add
+// that returns nothing, which the L2 takes at its own pace, instead of a compare-and-swap loop per touch whose
+// round trips a dozen rays through one cell (and four cells to a word) retry against each other: 2400 rays of the
+// reference's camera took 61 us that way on an empty local map. A second launch walks the counters, applies
+// count * inc with one clamp to every cell that has one (a byte store: its neighbours in the word belong to other
+// threads) and zeroes it again. (A list of the counted cells instead of the walk was tried first: its length is
+// one counter that every wave adds to, a few thousand adds to one address in a row at the L2: 65 us again.)
+__device__ inline void count_cell(const PfUpdateWork& uw, long long f, unsigned k) {
+    if (f >= 0 && k) (void)__hip_atomic_fetch_add(uw.cnt + f, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline long long near_flat(int slot, int cx, int cy, int cz, const PfUpdateParams& up) {
+    const int bz = slot % PF_NEAR_W, by = (slot / PF_NEAR_W) % PF_NEAR_W, bx = slot / (PF_NEAR_W * PF_NEAR_W);
+    return (long long)(bx + cx - PF_NEAR_R) * up.gy * up.gz + (long long)(by + cy - PF_NEAR_R) * up.gz + (bz + cz - PF_NEAR_R);
+}
+// 1024 threads to a workgroup. Workgroups 0 .. near_wgs-1 take the first near_steps steps of the rays b, b + near_wgs,
+// ... into d5_rays_near's LDS table, a thread per (ray, step) -- a thread per ray walked its 14 steps as one dependent
+// chain of fp64 roundings on a SIMD with nothing else to run, 5 us per pass, and 256 threads took 140 trips to read
+// the table back: 25 us, the launch's critical path -- and then add the table's counts to the cells' counters. The
+// others march 32 rays each from step near_steps + 1, PF_RAY_LANES lanes to a ray (d5_rays' loop).
+#define RAYS_COUNT_THREADS 1024
+#define NEAR_TBL_QUADS ((PF_NEAR_TBL_WORDS + 3) / 4)
+__global__ __launch_bounds__(RAYS_COUNT_THREADS) void k_rays_count(PfUpdateWork uw) {
+    __shared__ uint4 tbl4[NEAR_TBL_QUADS];
+    unsigned* tbl = (unsigned*)tbl4;
+    const PfUpdateParams& up = uw.up;
+    if ((int)blockIdx.x < uw.near_wgs) {
+        for (int k = threadIdx.x; k < NEAR_TBL_QUADS; k += RAYS_COUNT_THREADS) tbl4[k] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        const long long gyz = (long long)up.gy * up.gz;
+        const int gx = (int)(up.elements / gyz);
+        const double cxd = round(up.pos[0] * up.conv), cyd = round(up.pos[1] * up.conv), czd = round(up.pos[2] * up.conv);
+        const bool centre_ok = fabs(cxd) < 1e9 && fabs(cyd) < 1e9 && fabs(czd) < 1e9;
+        const int cx = centre_ok ? (int)cxd : 0, cy = centre_ok ? (int)cyd : 0, cz = centre_ok ? (int)czd : 0;
+        const int per = (uw.R - (int)blockIdx.x + uw.near_wgs - 1) / uw.near_wgs;   // rays of this workgroup
+        for (int i = threadIdx.x; i < per * uw.near_steps; i += RAYS_COUNT_THREADS) {
+            const int r = (int)blockIdx.x + (i / uw.near_steps) * uw.near_wgs, j = 1 + i % uw.near_steps;
+            const double* e = uw.wpts + 3 * (size_t)uw.ray_idx[r];
+            const double dx = e[0] - up.pos[0], dy = e[1] - up.pos[1], dz = e[2] - up.pos[2];
+            const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+            const double nc = nrm * up.conv;
+            const double rr = round(nc);                                 // S3P:676
+            if (!(rr < 2147483648.0) || j >= (int)rr) continue;          // (also drops NaN)
+            const double sx = dx / nc, sy = dy / nc, sz = dz / nc;       // S3P:681-683
+            const double jd = (double)j;
+            const double X = round((up.pos[0] + sx * jd) * up.conv), Y = round((up.pos[1] + sy * jd) * up.conv),
+                         Z = round((up.pos[2] + sz * jd) * up.conv);     // S3P:687-690
+            if (!(fabs(X) < 2147483648.0 && fabs(Y) < 2147483648.0 && fabs(Z) < 2147483648.0)) continue;
+            const long long f = (long long)X * up.gy * up.gz + (long long)Y * up.gz + (long long)Z;
+            if (f < 0 || f >= up.elements) continue;                     // S3P:691
+            const int xi = (int)X, yi = (int)Y, zi = (int)Z;
+            const unsigned bx = (unsigned)(xi - cx + PF_NEAR_R), by = (unsigned)(yi - cy + PF_NEAR_R), bz = (unsigned)(zi - cz + PF_NEAR_R);
+            if (centre_ok && bx < PF_NEAR_W && by < PF_NEAR_W && bz < PF_NEAR_W && (unsigned)xi < (unsigned)gx &&
+                (unsigned)yi < (unsigned)up.gy && (unsigned)zi < (unsigned)up.gz) {
+                const unsigned slot = (bx * PF_NEAR_W + by) * PF_NEAR_W + bz;
+                atomicAdd(&tbl[slot >> 1], 1u << (16u * (slot & 1u)));
+            } else {
+                count_cell(uw, f, 1u);                                   // off an axis or outside the box: straight to its counter
+            }
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < NEAR_TBL_QUADS; q += RAYS_COUNT_THREADS) {
+            const uint4 t = tbl4[q];
+            if (!(t.x | t.y | t.z | t.w)) continue;
+            const unsigned ws[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned c = (ws[k >> 1] >> (16u * (unsigned)(k & 1))) & 0xffffu;
+                const int slot = 8 * q + k;
+                if (c && slot < PF_NEAR_W * PF_NEAR_W * PF_NEAR_W) count_cell(uw, near_flat(slot, cx, cy, cz, up), c);
+            }
+        }
+        return;
+    }
+    const int r = ((int)blockIdx.x - uw.near_wgs) * (RAYS_COUNT_THREADS / PF_RAY_LANES) + (int)threadIdx.x / PF_RAY_LANES;
+    const int lane = (int)threadIdx.x % PF_RAY_LANES;
+    if (r >= uw.R) return;
+    const double* e = uw.wpts + 3 * (size_t)uw.ray_idx[r];
+    const double dx = e[0] - up.pos[0], dy = e[1] - up.pos[1], dz = e[2] - up.pos[2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    const double nc = nrm * up.conv;
+    const double rr = round(nc);                                         // S3P:676
+    if (!(rr < 2147483648.0)) return;                                    // also drops NaN
+    const int n_it = (int)rr;
+    const double sx = dx / nc, sy = dy / nc, sz = dz / nc;               // S3P:681-683
+    for (int j = 1 + uw.near_steps + lane; j < n_it; j += PF_RAY_LANES) {
+        const double jd = (double)j;
+        count_cell(uw, flat_of((up.pos[0] + sx * jd) * up.conv, (up.pos[1] + sy * jd) * up.conv,
+                               (up.pos[2] + sz * jd) * up.conv, up), 1u);   // S3P:687-691
+    }
+}
+// four counters to a thread and trip; elements4 = ceil(elements / 4) (the allocation is padded to it)
+__global__ __launch_bounds__(256) void k_rays_apply(PfUpdateWork uw, long long elements4) {
+    const PfUpdateParams& up = uw.up;
+    uint4* cnt4 = (uint4*)uw.cnt;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < elements4; q += (long long)gridDim.x * 256) {
+        const uint4 c = cnt4[q];
+        if (!(c.x | c.y | c.z | c.w)) continue;
+        cnt4[q] = make_uint4(0u, 0u, 0u, 0u);
+        const unsigned ks[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned k = ks[t];
+            const long long f = 4 * q + t;
+            if (!k || f >= up.elements) continue;
+            // k misses (S3P:695-700) = one of k * inc; beyond 256 of them the clamp has long been reached
+            const int step = (int)(k < 256u ? k : 256u) * up.miss_inc;
+            if (up.is_signed) {
+                int8_t* g = (int8_t*)uw.grid + f;
+                const int v = *g; int nv = v + step;
+                if (nv < up.miss_clamp) nv = up.miss_clamp;
+                if (nv != v) *g = (int8_t)nv;
+            } else {
+                uint8_t* g = (uint8_t*)uw.grid + f;
+                const int v = *g; int nv = v + step;
+                if (nv < up.miss_clamp) nv = up.miss_clamp;
+                if (nv != v) *g = (uint8_t)nv;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fill_u8(uint4* dst, unsigned long long n16, uint4 v) {
     for (unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x; k < n16;
          k += (unsigned long long)gridDim.x * 256)
@@ -999,6 +1122,21 @@ hipError_t pfk_update_hits(hipStream_t st, const PfUpdateWork& uw) {
 }
 hipError_t pfk_update_rays(hipStream_t st, const PfUpdateWork& uw) {
     if (uw.R == 0) return hipSuccess;
+    if (uw.cnt) {
+        PfUpdateWork w = uw;
+        // few rays: the table's fixed cost (clear, 140 reads per thread to flush) is not worth it; a ray stays in a
+        // cell for two steps at most, so a workgroup's 16-bit table counters hold up to 32 767 rays
+        const bool near = uw.R >= 256 && uw.R <= (1 << 20);
+        w.near_steps = near ? PF_NEAR_STEPS : 0;
+        // (2400 rays: 8 near workgroups 13.9 us, 16: 11.0, 32: 10.7; the march alone 8.7)
+        w.near_wgs = near ? (uw.R / 150 < 8 ? 8 : uw.R / 150 > 64 ? 64 : uw.R / 150) : 0;
+        const int per_wg = RAYS_COUNT_THREADS / PF_RAY_LANES;
+        hipLaunchKernelGGL(k_rays_count, dim3(w.near_wgs + (uw.R + per_wg - 1) / per_wg), dim3(RAYS_COUNT_THREADS), 0, st, w);
+        const long long e4 = (uw.up.elements + 3) / 4;
+        // two trips per thread (3.2 M counters: 4.0 us; eight trips 6.9 us)
+        hipLaunchKernelGGL(k_rays_apply, dim3((unsigned)(e4 / 512 < 1 ? 1 : e4 / 512 > 8192 ? 8192 : e4 / 512)), dim3(256), 0, st, w, e4);
+        return hipGetLastError();
+    }
     // SLAM_PF_NEAR=0: every step by compare-and-swap (comparison); few rays: not worth the table
     static const bool near_wanted = !(getenv("SLAM_PF_NEAR") && atoi(getenv("SLAM_PF_NEAR")) == 0);
     // (the eight near workgroups take every ray's first steps, 2048 threads in all: beyond a ray or two per thread they
@@ -1030,14 +1168,16 @@ hipError_t pfk_fill_u8(hipStream_t st, uint8_t* dst, unsigned long long n, int v
 // (S3P:332, matrices from the host libm), then one workgroup per hypothesis, lanes over points,
 // integer block reduction. Same flat-only bounds rule (S3P:358: >=).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_vote_rotate(const double* __restrict__ points, int N,
+__global__ __launch_bounds__(256) void k_vote_rotate(const double* __restrict__ points,
+                                                     const int32_t* __restrict__ pick, int N,
                                                      const double* __restrict__ mats,
                                                      double* __restrict__ rot) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int r = blockIdx.y;
     if (i >= N) return;
     const double* m = mats + 9 * r;
-    const double px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
+    const size_t src = pick ? (size_t)pick[i] : (size_t)i;   // S3P:320-322: the drawn rows of the cloud
+    const double px = points[3 * src], py = points[3 * src + 1], pz = points[3 * src + 2];
     double* o = rot + 3 * ((size_t)r * N + i);
     o[0] = m[0] * px + m[1] * py + m[2] * pz;             // S3P:547-549
     o[1] = m[3] * px + m[4] * py + m[5] * pz;
@@ -1068,12 +1208,12 @@ __global__ __launch_bounds__(256) void k_vote(const uint8_t* __restrict__ grid,
     __syncthreads();
     if (threadIdx.x == 0) sums[hyp] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-hipError_t pfk_scan_vote(hipStream_t st, const uint8_t* grid, const double* points, int N,
+hipError_t pfk_scan_vote(hipStream_t st, const uint8_t* grid, const double* points, const int32_t* pick, int N,
                          const double* mats, int n_yaw, const double* trans, int n_per_yaw,
                          double conv, int gy, int gz, long long elements, double* rot,
                          int32_t* sums) {
     if (N > 0)
-        hipLaunchKernelGGL(k_vote_rotate, dim3((N + 255) / 256, n_yaw), dim3(256), 0, st, points, N,
+        hipLaunchKernelGGL(k_vote_rotate, dim3((N + 255) / 256, n_yaw), dim3(256), 0, st, points, pick, N,
                            mats, rot);
     hipLaunchKernelGGL(k_vote, dim3(n_yaw * n_per_yaw), dim3(256), 0, st, grid, rot, N, trans,
                        n_per_yaw, conv, gy, gz, elements, sums);
@@ -1139,6 +1279,19 @@ __global__ __launch_bounds__(1024) void k_ring_shift(int32_t* slot, int count, l
     }
     if (tid == 0) *count_out = base_s;
 }
+// S3P:305-312 in one launch: blockIdx.y names the live slot
+__global__ __launch_bounds__(256) void k_ring_paint(uint8_t* __restrict__ grid, const int32_t* __restrict__ ring,
+                                                    PfRingPaint rp) {
+    const int s = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j < rp.count[s]) grid[ring[(size_t)rp.slot[s] * rp.cap + j]] = 1;
+}
+hipError_t pfk_ring_paint(hipStream_t st, uint8_t* grid, const int32_t* ring, const PfRingPaint& rp) {
+    int most = 0;
+    for (int s = 0; s < rp.n; ++s) most = rp.count[s] > most ? rp.count[s] : most;
+    if (rp.n <= 0 || most <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ring_paint, dim3((most + 255) / 256, rp.n), dim3(256), 0, st, grid, ring, rp);
+    return hipGetLastError();
+}
 hipError_t pfk_ring_set(hipStream_t st, uint8_t* grid, const int32_t* slot, int count, int value) {
     if (count <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_ring_set, dim3((count + 255) / 256), dim3(256), 0, st, grid, slot, count, value);
@@ -1162,11 +1315,8 @@ hipError_t pfk_ring_shift(hipStream_t st, int32_t* slot, int count, long long co
 // with the pinhole tables truncated toward zero (S3P:567-568); then an order-preserving
 // compaction of the pixels with a depth (S3P:598-611) in one workgroup.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_depth_pool(const uint8_t* __restrict__ image, int width,
-                                                    int res_h, int res_v, int pool, double focal,
-                                                    int4* __restrict__ dpix) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= res_h * res_v) return;
+__device__ inline int depth_pixel(const uint8_t* __restrict__ image, int width, int res_h, int res_v, int pool,
+                                  double focal, int p, int4* __restrict__ dpix) {
     const int i = p / res_h, j = p - i * res_h;
     int int_sum = 0, devide_sum = 0;
     for (int a = 0; a < pool; ++a) {
@@ -1181,6 +1331,53 @@ __global__ __launch_bounds__(256) void k_depth_pool(const uint8_t* __restrict__ 
     const double horizontal = ((j + 1) - (res_h / 2)) / focal;             // S3P:158
     const double vertical = -1 * ((i + 1) - (res_v / 2)) / focal;          // S3P:161
     dpix[p] = make_int4((int)(depth_y * horizontal), depth_y, (int)(depth_y * vertical), 0);
+    return depth_y;
+}
+// bcnt (may be null): the number of pixels with a depth in each workgroup's 256, for k_depth_place
+__global__ __launch_bounds__(256) void k_depth_pool(const uint8_t* __restrict__ image, int width,
+                                                    int res_h, int res_v, int pool, double focal,
+                                                    int4* __restrict__ dpix, int32_t* __restrict__ bcnt) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (bcnt) {                                    // (no early return: every lane reaches the ballot)
+        __shared__ int wc[4];
+        int depth = 0;
+        if (p < res_h * res_v) depth = depth_pixel(image, width, res_h, res_v, pool, focal, p, dpix);
+        const int c = __popcll(__ballot(depth != 0));
+        if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) bcnt[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+        return;
+    }
+    if (p < res_h * res_v) depth_pixel(image, width, res_h, res_v, pool, focal, p, dpix);
+}
+// The order-preserving compaction (S3P:598-611) with one workgroup per 256 pixels: the pixels kept before a
+// workgroup's own are the sum of the earlier workgroups' counts (k_depth_pool left them; at most 1024 of them
+// here, the host takes the one-workgroup form below for larger images), the rank inside is a ballot per wave.
+__global__ __launch_bounds__(256) void k_depth_place(const int4* __restrict__ dpix, int npix,
+                                                      const int32_t* __restrict__ bcnt,
+                                                      double* __restrict__ cloud, int32_t* count_out) {
+    __shared__ int part[4];
+    __shared__ int wc[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int before = 0;
+    for (int k = tid; k < (int)blockIdx.x; k += 256) before += bcnt[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    const int p = blockIdx.x * 256 + tid;
+    int4 d = make_int4(0, 0, 0, 0);
+    if (p < npix) d = dpix[p];
+    const bool keep = d.y != 0;                                              // S3P:602
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) { part[wv] = before; wc[wv] = __popcll(m); }
+    __syncthreads();
+    int base = part[0] + part[1] + part[2] + part[3];
+    for (int k = 0; k < wv; ++k) base += wc[k];
+    if (keep) {
+        double* o = cloud + 3 * (size_t)(base + __popcll(m & ((1ull << lane) - 1ull)));
+        o[0] = d.x / 1000.0; o[1] = d.y / 1000.0; o[2] = d.z / 1000.0;       // S3P:603-605
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0)
+        *count_out = part[0] + part[1] + part[2] + part[3] + wc[0] + wc[1] + wc[2] + wc[3];
 }
 // Rounds of up to 32 tiles of 1024 pixels: every thread first reads the depth of its pixel in each tile of the
 // round (independent loads, all in flight: the one-tile-at-a-time form took 27 us for the reference's 19 200
@@ -1229,12 +1426,35 @@ __global__ __launch_bounds__(1024) void k_depth_compact(const int4* __restrict__
     if (tid == 0) *count_out = base_s;
 }
 hipError_t pfk_depth_to_cloud(hipStream_t st, const uint8_t* image, int width, int height, int pool,
-                              double focal, int4* dpix, double* cloud, int32_t* count_out) {
+                              double focal, int4* dpix, double* cloud, int32_t* count_out, int32_t* bcnt) {
     const int res_h = width / pool, res_v = height / pool, npix = res_h * res_v;
     if (npix <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_depth_pool, dim3((npix + 255) / 256), dim3(256), 0, st, image, width, res_h, res_v,
-                       pool, focal, dpix);
+    const int nb = (npix + 255) / 256;
+    if (bcnt && nb <= 1024) {
+        hipLaunchKernelGGL(k_depth_pool, dim3(nb), dim3(256), 0, st, image, width, res_h, res_v, pool, focal, dpix, bcnt);
+        hipLaunchKernelGGL(k_depth_place, dim3(nb), dim3(256), 0, st, dpix, npix, bcnt, cloud, count_out);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_depth_pool, dim3(nb), dim3(256), 0, st, image, width, res_h, res_v,
+                       pool, focal, dpix, (int32_t*)nullptr);
     hipLaunchKernelGGL(k_depth_compact, dim3(1), dim3(1024), 0, st, dpix, npix, cloud, count_out);
+    return hipGetLastError();
+}
+
+// A cloud that is already on the device becomes a handle's scan (pf_set_scan_device): the copy keeps the bound
+// the host form checks before it uploads (|coordinate| < 1e6, which bounds a ray's march): a coordinate outside
+// it is stored as NaN, and a point with a NaN contributes no hit and no ray (d5_hits, d5_rays: "drops NaN").
+__global__ __launch_bounds__(256) void k_copy_points(const double* __restrict__ src, long long n3,
+                                                     double* __restrict__ dst) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n3) return;
+    const double v = src[k];
+    dst[k] = fabs(v) < 1.0e6 ? v : __longlong_as_double(0x7ff8000000000000ll);
+}
+hipError_t pfk_copy_points(hipStream_t st, const double* src, int n, double* dst) {
+    if (n <= 0) return hipSuccess;
+    const long long n3 = 3ll * n;
+    hipLaunchKernelGGL(k_copy_points, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, src, n3, dst);
     return hipGetLastError();
 }
 

@@ -128,7 +128,7 @@ extern "C" int pf_scan_vote_static(int32_t device, void* hip_stream, const uint8
     hipLaunchKernelGGL(k_vote_setup, dim3((setup_items + 255) / 256), dim3(256), 0, st, s, d_m, d_t);
     e = hipGetLastError();
     if (e == hipSuccess)
-        e = pfk_scan_vote(st, grid_dev, points_dev, (int)n_points, d_m, n_yaw, d_t, per, 1 / resolution, gy, gz,
+        e = pfk_scan_vote(st, grid_dev, points_dev, nullptr, (int)n_points, d_m, n_yaw, d_t, per, 1 / resolution, gy, gz,
                           (long long)gx * gy * gz, d_r, sums_dev);
     if (e != hipSuccess) { pfk_set_global_error(hipGetErrorString(e)); return PF_ERR_HIP; }
     return PF_OK;

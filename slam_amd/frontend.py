@@ -10,6 +10,10 @@ while the loops go to the GPU through the C ABI (include/slam_pf.h) in the refer
     pf_set_scan, pf_update_map         build_local_map                           S3P:621-704
     pfh_update_realtime_pos            update_realtime_pos                       S3P:712-728
 
+With device_cloud=True the cloud (S3P:126) never leaves the GPU: the pf_*_device forms of the same calls work on
+one device buffer, the two handles share `loc`'s stream, and per frame only the point count, the vote's sums and
+the ring's count come back to the host (results identical, tests/test_gpu_frontend.py).
+
 `loc` is a PF_MAP_SHARED handle holding the binary localisation grid (S3P:64) with its keyframe
 ring; `mapper` is the handle whose int8 local map (S3P:65) build_local_map() writes — the filter's
 own handle in the reference's layout. Both are slam_amd.capi.Handle objects (or, in the CPU suite,
@@ -27,8 +31,9 @@ N_RAYS = 2400                                                        # S3P:668
 
 class FrameLoop:
     def __init__(self, loc, mapper, width=640, height=480, pool=4, focal=385.0 / 4.0, resolution=0.05,
-                 map_size=(10, 10, 4), replay=False):
+                 map_size=(10, 10, 4), replay=False, device_cloud=False):
         self.loc, self.mapper = loc, mapper
+        self.device_cloud = bool(device_cloud)
         # replay: the index draws keep the reference's inclusive upper bound n (S3P:317, 666), for seeds known not to
         # draw it (the golden fixtures); default: draws in [0, n-1], which any seed serves
         self.replay = replay
@@ -54,12 +59,32 @@ class FrameLoop:
         self.update_params = capi.UpdateParams(10, 50, -3, -50, 3.0)  # S3P:637, 650-655, 695-700
         self.n = 0
         # cloudpoints (S3P:126): rows beyond the current count keep what earlier frames left there
-        self.cloud = np.zeros(((width // pool) * (height // pool) + 1, 3), np.float64)
+        self.capacity = (width // pool) * (height // pool)
+        if self.device_cloud:
+            import torch      # device memory only: the buffer the four pf_*_device calls share
+            self.cloud = None
+            self._cloud_dev = torch.zeros((self.capacity + 1) * 3, dtype=torch.float64,
+                                          device=torch.device("cuda", int(loc.cfg.device)))
+            torch.cuda.synchronize()
+            self.cloud_ptr = self._cloud_dev.data_ptr()
+            mapper.set_stream(loc.stream())              # one stream orders the buffer's writer and its readers
+        else:
+            self.cloud = np.zeros((self.capacity + 1, 3), np.float64)
         self.last_vote = -1
         self.last_flags = 0
 
+    def close(self):
+        """device_cloud: the mapper goes back to its own stream (call before `loc`, whose stream it borrowed, is closed)."""
+        if self.device_cloud and self.mapper is not None:
+            self.mapper.set_stream(None)
+            self.device_cloud = False
+
     # ---- S3P:173-185 ----
     def depth(self, image):
+        if self.device_cloud:
+            self.n = self.loc.depth_to_cloud_device(image, self.width, self.height, self.cloud_ptr, self.capacity,
+                                                    self.pool, self.focal)
+            return None
         c = self.loc.depth_to_cloud(image, self.width, self.height, self.pool, self.focal)
         self.n = len(c)
         self.cloud[:self.n] = c
@@ -79,9 +104,12 @@ class FrameLoop:
         # S3P:315-319 draws in [0, n] inclusive, one row past the cloud; replay=True keeps that (fixture seeds are
         # screened so that row n is never drawn); otherwise the draw is in [0, n-1] like driver/step_loop.cpp's
         pick = capi.draw_indices(seed, N_SCAN_POINTS, self.n if self.replay else self.n - 1)
-        sample = self.cloud[pick]                                                    # S3P:320-322
         zyx = (self.yaw_scan, self.rot_y, self.rot_x)
-        _, best = self.loc.scan_vote(sample, self.pos_scan, zyx, **VOTE)             # S3P:328-376
+        if self.device_cloud:                                                        # S3P:320-322 on the device
+            _, best = self.loc.scan_vote_device(self.cloud_ptr, self.n, pick, self.pos_scan, zyx, **VOTE)
+        else:
+            sample = self.cloud[pick]                                                # S3P:320-322
+            _, best = self.loc.scan_vote(sample, self.pos_scan, zyx, **VOTE)         # S3P:328-376
         hyp = capi.vote_hypothesis(best, self.pos_scan, zyx, self.resolution, **VOTE)
         if hyp is not None:                                                          # S3P:365-372
             self.vote_loc[:] = hyp
@@ -94,7 +122,10 @@ class FrameLoop:
     # ---- scan_localization_map_update(): S3P:419-529 ----
     def map_update(self):
         zyx = (self.yaw_scan, self.rot_y, self.rot_x)
-        self.last_flags, self.pos_scan = self.loc.ring_update(self.cloud[:self.n], self.pos_scan, zyx)
+        if self.device_cloud:
+            self.last_flags, self.pos_scan = self.loc.ring_update_device(self.cloud_ptr, self.n, self.pos_scan, zyx)
+        else:
+            self.last_flags, self.pos_scan = self.loc.ring_update(self.cloud[:self.n], self.pos_scan, zyx)
         return self.last_flags
 
     # ---- build_local_map(): S3P:621-710 (the caller holds its mutex around this, S3P:622/708) ----
@@ -105,7 +136,10 @@ class FrameLoop:
         if np.any(rays >= self.n):
             raise ValueError("a ray index names the row behind the cloud (S3P:666 draws it; the reference then "
                              "marches to a stale point): replay=True is for seeds screened against that")
-        self.mapper.set_scan(self.cloud[:self.n], rays)
+        if self.device_cloud:
+            self.mapper.set_scan_device(self.cloud_ptr, self.n, rays)
+        else:
+            self.mapper.set_scan(self.cloud[:self.n], rays)
         self.mapper.update_map(capi.PF_GRID_LOCAL, self.update_params, self.local_pos,
                                (self.local_yaw, self.rot_y, self.rot_x))             # S3P:628-704
         self.pos, self.yaw = capi.update_realtime_pos(self.pos, self.yaw, self.pos_diff_scan,

@@ -123,20 +123,21 @@ def check_ring_calls(golden_dir, loc):
 
 
 # ---- the whole loop: frames.npz ---------------------------------------------------------------
-def check_frames(golden_dir, loc, mapper, filter_backend=None, frames=None):
+def check_frames(golden_dir, loc, mapper, filter_backend=None, frames=None, device_cloud=False):
     """callback() per frame (S3P:168-205) and, with a filter backend, particle_map() after every
     per_step frames (S3P:1102-1111): every member the reference's run left after each call."""
     g = load(golden_dir, "frames.npz")
     F = int(g["frames"]) if frames is None else frames
     per_step, P = int(g["per_step"]), int(g["P"])
-    fl = FrameLoop(loc, mapper, replay=True)
+    fl = FrameLoop(loc, mapper, replay=True, device_cloud=device_cloud)
     st = ParticleMapStep(filter_backend, P) if filter_backend is not None else None
     if st is not None:
         st.set_state(np.full(P, 7.5), np.full(P, 7.5), np.full(P, 1.5), np.zeros(P), np.full(P, 1.0 / P))
     k = 0
     for f in range(F):
         fl.depth(full_image(g["pooled"][f]))
-        assert fl.n == int(g["n"][f]) and crc(fl.cloud[:fl.n]) == int(g["cloud_crc"][f]), f
+        cloud = fl._cloud_dev[:3 * fl.n].cpu().numpy() if device_cloud else fl.cloud[:fl.n]
+        assert fl.n == int(g["n"][f]) and crc(cloud) == int(g["cloud_crc"][f]), f
         fl.set_gyr(g["gyr"][f])
         pick = fl.scan_localization(int(g["seed_vote"][f]))
         assert crc(pick) == int(g["pick_crc"][f]), f

@@ -37,6 +37,26 @@ def test_depth_front_end_matches_reference(golden_dir):
         h.close()
 
 
+def test_depth_front_end_at_other_image_sizes():
+    """The compaction's two forms (one workgroup per 256 pooled pixels up to 262 144 of them, one workgroup for all
+    beyond) against the oracle's loop: a 700 x 420 image unpooled (294 000 pixels), the same pooled by 2, a
+    one-pixel image, an all-zero image."""
+    from oracle import binding as O
+    rng = np.random.default_rng(3)
+    h = loc_handle()
+    try:
+        for width, height, pool, zero in ((700, 420, 1, 0.4), (700, 420, 2, 0.4), (1, 1, 1, 0.0), (64, 48, 4, 1.0),
+                                          (640, 480, 4, 0.97)):
+            img = rng.integers(300, 9000, (height, width)).astype(np.uint16)
+            img[rng.random((height, width)) < zero] = 0
+            raw = np.frombuffer(img.astype("<u2").tobytes(), np.uint8)
+            want = O.depth_to_cloud(raw, width, height, pool, 385.0 / pool)
+            got = h.depth_to_cloud(raw, width, height, pool, 385.0 / pool)
+            assert got.shape == want.shape and np.array_equal(got, want), (width, height, pool)
+    finally:
+        h.close()
+
+
 def test_scan_vote_matches_reference(golden_dir):
     G.check_vote_cases(golden_dir, loc_handle)
 
@@ -109,6 +129,78 @@ def test_callback_and_particle_loop_matches_reference(golden_dir):
         G.check_frames(golden_dir, loc, flt, flt)
     finally:
         loc.close(); flt.close()
+
+
+def test_callback_with_the_cloud_kept_on_the_gpu_matches_reference(golden_dir):
+    """The same 48 frames and 6 filter steps through pf_depth_to_cloud_device, pf_scan_vote_device,
+    pf_ring_update_device and pf_set_scan_device: the cloud (S3P:126) stays in one device buffer, the two handles
+    share a stream, and every member, ring entry and map still equals the reference's after every call."""
+    loc, flt = loc_handle(), mapper_handle(50)
+    try:
+        G.check_frames(golden_dir, loc, flt, flt, device_cloud=True)
+    finally:
+        flt.set_stream(None)                     # it borrowed loc's stream
+        loc.close(); flt.close()
+
+
+def test_device_cloud_forms_equal_the_host_forms_and_check_their_arguments(golden_dir):
+    """Each pf_*_device call beside its host form on one cloud, and what the device forms do where the host
+    forms would have refused: indices outside the cloud are refused all the same; a coordinate that is not
+    finite or beyond 1e6 (nobody on the host sees it) makes its point contribute nothing."""
+    import torch
+    g = G.load(golden_dir, "local_map.npz")
+    cloud = G.cloud_of(g["m0_fresh_cloud_mm"]); rays = g["m0_fresh_rays"]
+    n = len(cloud)
+    dev = torch.from_numpy(cloud.reshape(-1)).cuda()
+    rng = np.random.default_rng(11)
+    pos, zyx = np.array([5.0, 5.1, 1.6]), np.array([0.2, 0.01, -0.02])
+    a, b = loc_handle(), loc_handle()
+    try:
+        grid = (rng.random(200 * 200 * 80) < 0.03).astype(np.uint8)
+        a.write_map(0, grid); b.write_map(0, grid)
+        pick = rng.integers(0, n, 500).astype(np.int32)
+        sa, ba = a.scan_vote(cloud[pick], pos, zyx)
+        sb, bb = b.scan_vote_device(dev.data_ptr(), n, pick, pos, zyx)
+        assert np.array_equal(sa, sb) and ba == bb and sa.max() > 0
+        s0, b0 = b.scan_vote_device(dev.data_ptr(), n, pick[:0], pos, zyx)
+        assert not s0.any() and b0 == -1
+        for bad in ([-1], [n]):
+            with pytest.raises(capi.PfError):
+                b.scan_vote_device(dev.data_ptr(), n, np.array(bad, np.int32), pos, zyx)
+        fa, pa = a.ring_update(cloud, pos, zyx)
+        fb, pb = b.ring_update_device(dev.data_ptr(), n, pos, zyx)
+        assert fa == fb and np.array_equal(pa, pb)
+        ra, rb = a.ring_state(with_idx=True), b.ring_state(with_idx=True)
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb)) and ra[0].sum() > 0
+        with pytest.raises(capi.PfError):
+            b.ring_update_device(dev.data_ptr(), 19201, pos, zyx)
+    finally:
+        a.close(); b.close()
+    a, b = mapper_handle(), mapper_handle()
+    try:
+        params = capi.UpdateParams(10, 50, -3, -50, 3.0)
+        a.set_scan(cloud, rays); a.update_map(capi.PF_GRID_LOCAL, params, pos, zyx)
+        b.set_scan_device(dev.data_ptr(), n, rays); b.update_map(capi.PF_GRID_LOCAL, params, pos, zyx)
+        want = a.read_local_map()
+        assert np.array_equal(want, b.read_local_map()) and np.count_nonzero(want) > 1000
+        for bad in ([-1], [n]):
+            with pytest.raises(capi.PfError):
+                b.set_scan_device(dev.data_ptr(), n, np.array(bad, np.int32))
+        # wild coordinates: the points that hold them drop out, the others act as before
+        wild = cloud.copy()
+        rows = np.array([3, 700, 701, n - 1]); vals = [np.nan, np.inf, -2.0e6, 1.0e6]
+        for r, v in zip(rows, vals):
+            wild[r, r % 3] = v
+        keep = np.setdiff1d(np.arange(n), rows)
+        renum = np.full(n, -1, np.int64); renum[keep] = np.arange(len(keep))
+        rays_kept = renum[rays[np.isin(rays, keep)]].astype(np.int32)
+        a.reset_local_map(); b.reset_local_map()
+        a.set_scan(cloud[keep], rays_kept); a.update_map(capi.PF_GRID_LOCAL, params, pos, zyx)
+        wdev = torch.from_numpy(wild.reshape(-1)).cuda()
+        b.set_scan_device(wdev.data_ptr(), n, rays); b.update_map(capi.PF_GRID_LOCAL, params, pos, zyx)
+        assert np.array_equal(a.read_local_map(), b.read_local_map())
+    finally:
+        a.close(); b.close()
 
 
 def test_scan_vote_leaves_the_scan_alone(golden_dir):

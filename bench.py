@@ -426,6 +426,36 @@ def frame_leg(reps=3):
                                      "frac": b["local_map"] / (out["kernel_us"]["local_map"] * 1e-6) / 8e12 if out["kernel_us"]["local_map"] > 0 else None}}
     out["note"] = ("every stage is launch- and copy-bound at the reference's sizes: the kernels take a few us of a call whose "
                    "host side draws indices, uploads the image or a few hundred bytes and waits for a count or 625 sums")
+    # the same loop without the Python around it: driver/step_loop.cpp replays the 48 frames (and the 6 filter steps
+    # between them, outside its callback timer) and reports the wall time per callback()
+    exe = os.path.join(ROOT, "driver", "step_loop")
+    if os.path.exists(exe):
+        import struct, subprocess, tempfile
+        with tempfile.NamedTemporaryFile(suffix=".replay") as fp:
+            fp.write(struct.pack("<iii", F, int(g["per_step"]), int(g["P"])))
+            fp.write(np.ascontiguousarray(g["pooled"], "<u2").tobytes())
+            fp.write(np.ascontiguousarray(g["gyr"], "<f8").tobytes())
+            for k in ("seed_vote", "seed_rays", "step_seed"):
+                fp.write(np.ascontiguousarray(g[k]).astype("<u4").tobytes())
+            fp.flush()
+            drv = {}
+            for mode, key in (("replay-device", "us_per_frame"), ("replay", "us_per_frame_host_cloud")):
+                best_us = None
+                for rep in range(reps):
+                    r = subprocess.run([exe, mode, fp.name], capture_output=True, text=True, timeout=120)
+                    if r.returncode != 0:
+                        break
+                    for line in r.stderr.splitlines():
+                        if line.startswith("callback():"):
+                            us = float(line.split("us each,")[1].split("us")[0])     # the frames after the first filter step
+                            best_us = us if best_us is None else min(best_us, us)
+                if best_us is not None:
+                    drv[key] = best_us
+            if drv:
+                drv["what"] = ("driver/step_loop.cpp (the C++ caller) on the same 48 frames, a fresh process per run; wall time per "
+                               "callback() body over the 40 frames after the first filter step (the first eight load code objects "
+                               "and allocate scratch)")
+                out["cpp_driver"] = drv
     # the reference's own callback sequence on this host
     so = os.path.join(ROOT, "oracle", "_ref", "libs3p_ref.so")
     if os.path.exists(so):

@@ -27,8 +27,15 @@
 //   index draws, per step the seed of the motion noise (the thresholds use seed + 1); prints every
 //   frame's global pose and every step's result at 17 digits. tests/test_gpu_driver.py writes such a
 //   file from tests/golden/frames.npz, the reference's own 48-frame run, and compares.
+//   ./step_loop replay-device <file>            the same with cloudpoints (S3P:126) kept in a device buffer
+//   between the stages (pf_depth_to_cloud_device, pf_scan_vote_device, pf_ring_update_device,
+//   pf_set_scan_device; both handles on one stream): same printed numbers.
+//   Every mode ends with the wall time per callback() on stderr.
 #include "../include/slam_pf.h"
 
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -140,7 +147,8 @@ void expand_pooled(const uint16_t* pooled, std::vector<uint8_t>& img) {
 
 int main(int argc, char** argv) {
     Replay rep;
-    const bool replay = argc > 2 && std::strcmp(argv[1], "replay") == 0;
+    const bool device_cloud = argc > 2 && std::strcmp(argv[1], "replay-device") == 0;
+    const bool replay = argc > 2 && (device_cloud || std::strcmp(argv[1], "replay") == 0);
     if (replay && !load_replay(argv[2], rep)) {
         std::fprintf(stderr, "cannot read the replay file %s\n", argv[2]);
         return 1;
@@ -179,6 +187,16 @@ int main(int argc, char** argv) {
 
     const int L = cfg.local_x * cfg.local_y * cfg.local_z;
     const int npix = (kW / kPool) * (kH / kPool);
+    double* cloud_dev = nullptr;                 // cloudpoints (S3P:126) in HBM
+    if (device_cloud) {
+        if (hipSetDevice(cfg.device) != hipSuccess || hipMalloc((void**)&cloud_dev, sizeof(double) * 3 * ((size_t)npix + 1)) != hipSuccess) {
+            std::fprintf(stderr, "hipMalloc of the cloud failed\n");
+            return 1;
+        }
+        CK(h, pf_set_stream(h, pf_stream(loc)));   // one stream orders the cloud's writer and its readers
+    }
+    double callback_s = 0, warm_s = 0;           // all frames; the frames after the first filter step (code objects loaded,
+    long callbacks = 0, warm = 0;                //  scratch allocated)
     std::vector<int8_t> local((size_t)L);
     std::vector<int32_t> bx((size_t)L), by((size_t)L), bz((size_t)L), slots((size_t)P);
     std::vector<int8_t> bv((size_t)L);
@@ -213,7 +231,9 @@ int main(int argc, char** argv) {
                 synth_depth(truth[0], truth[1], truth[2], truth[3], img);
             }
             int64_t n = 0;
-            CK(loc, pf_depth_to_cloud(loc, img.data(), kW, kH, kPool, kFocal, cloud.data(), npix, &n));   // S3P:173-175
+            const auto t_cb = std::chrono::steady_clock::now();
+            if (device_cloud) CK(loc, pf_depth_to_cloud_device(loc, img.data(), kW, kH, kPool, kFocal, cloud_dev, npix, &n));
+            else CK(loc, pf_depth_to_cloud(loc, img.data(), kW, kH, kPool, kFocal, cloud.data(), npix, &n));   // S3P:173-175
             double pos_diff_scan[3] = {0, 0, 0}, yaw_diff = 0;
             if (truth_odometry) {
                 pos_diff_scan[0] = std::cos(-truth[3] + d[3]) * d[0] - std::sin(-truth[3] + d[3]) * d[1];
@@ -228,10 +248,14 @@ int main(int argc, char** argv) {
                 // S3P:315-319 draws in [0, n] (one past the cloud); the driver's own seeds draw in [0, n-1],
                 // the recorded seeds were screened to stay below n
                 pfh_draw_indices(replay ? rep.seed_vote[(size_t)fno] : rd(), 500, (int32_t)(replay ? n : n - 1), pick.data());
-                for (int k = 0; k < 500; ++k)
-                    for (int c = 0; c < 3; ++c) sample[3 * (size_t)k + c] = cloud[3 * (size_t)pick[(size_t)k] + c];
                 int64_t hyp = -1;
-                CK(loc, pf_scan_vote(loc, sample.data(), 500, pos_scan, zyx, 5, -6, 3, 5, 0.25, nullptr, &hyp));
+                if (device_cloud) {                              // S3P:320-322 happens in the vote's rotation kernel
+                    CK(loc, pf_scan_vote_device(loc, cloud_dev, n, pick.data(), 500, pos_scan, zyx, 5, -6, 3, 5, 0.25, nullptr, &hyp));
+                } else {
+                    for (int k = 0; k < 500; ++k)
+                        for (int c = 0; c < 3; ++c) sample[3 * (size_t)k + c] = cloud[3 * (size_t)pick[(size_t)k] + c];
+                    CK(loc, pf_scan_vote(loc, sample.data(), 500, pos_scan, zyx, 5, -6, 3, 5, 0.25, nullptr, &hyp));
+                }
                 double out[4];
                 if (pfh_vote_hypothesis(hyp, pos_scan, zyx, 0.05, 5, -6, 3, 5, 0.25, out) == 0) {
                     std::memcpy(vote_loc, out, sizeof out);      // S3P:366-371; kept on "no vote"
@@ -243,7 +267,8 @@ int main(int argc, char** argv) {
                                   &yaw_diff_scan, &yaw_diff);                                   // S3P:379-404
                 int32_t flags = 0;
                 const double zyx_now[3] = {yaw_scan, rot_y, rot_x};
-                CK(loc, pf_ring_update(loc, cloud.data(), n, pos_scan, zyx_now, &flags));       // S3P:419-529
+                if (device_cloud) CK(loc, pf_ring_update_device(loc, cloud_dev, n, pos_scan, zyx_now, &flags));
+                else CK(loc, pf_ring_update(loc, cloud.data(), n, pos_scan, zyx_now, &flags));  // S3P:419-529
                 keyframes += flags & 1;
             }
             // build_local_map(): S3P:621-710
@@ -253,9 +278,13 @@ int main(int argc, char** argv) {
             for (int k = 0; k < 3; ++k) local_pos[k] += pos_diff_scan[k];                       // S3P:623-626
             local_yaw += yaw_diff;
             const double lzyx[3] = {local_yaw, rot_y, rot_x};
-            CK(h, pf_set_scan(h, cloud.data(), n, ray_idx.data(), n > 0 ? (int64_t)ray_idx.size() : 0));
+            if (device_cloud) CK(h, pf_set_scan_device(h, cloud_dev, n, ray_idx.data(), n > 0 ? (int64_t)ray_idx.size() : 0));
+            else CK(h, pf_set_scan(h, cloud.data(), n, ray_idx.data(), n > 0 ? (int64_t)ray_idx.size() : 0));
             CK(h, pf_update_map(h, PF_GRID_LOCAL, &upd, local_pos, lzyx));                      // S3P:628-704
             pfh_update_realtime_pos(pos, &pos[3], pos_diff_scan, yaw_diff, diff);              // S3P:712-728
+            const double dt_cb = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_cb).count();
+            callback_s += dt_cb; ++callbacks;
+            if (t > 0) { warm_s += dt_cb; ++warm; }
             if (replay) std::printf("frame %d gpose %.17g %.17g %.17g %.17g\n", fno, pos[0], pos[1], pos[2], pos[3]);
         }
         // ---- particle_map() (S3P:827-962) ----
@@ -301,6 +330,10 @@ int main(int argc, char** argv) {
     CK(h, pf_read_occupied(h, best, 80, 4, occ.data(), 1 << 20, &n_occ, &total_occ));
     std::printf("front end: %ld votes, %ld frames without a vote, %ld keyframes; published cloud: %lld points\n",
                 votes, no_votes, keyframes, (long long)total_occ);
+    std::fprintf(stderr, "callback(): %ld frames, %.1f us each, %.1f us after the first filter step (wall, host-inclusive%s)\n",
+                 callbacks, callbacks ? callback_s / callbacks * 1e6 : 0.0, warm ? warm_s / warm * 1e6 : 0.0,
+                 device_cloud ? ", cloud kept in HBM" : "");
+    if (device_cloud) { CK(h, pf_set_stream(h, nullptr)); (void)hipFree(cloud_dev); }
     pf_destroy(loc);
     pf_destroy(h);
     return 0;

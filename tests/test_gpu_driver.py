@@ -21,7 +21,10 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
 
-def test_cpp_driver_replays_the_reference_run(golden_dir, tmp_path):
+@pytest.mark.parametrize("mode", ["replay", "replay-device"])
+def test_cpp_driver_replays_the_reference_run(golden_dir, tmp_path, mode):
+    """mode replay-device: the same run with the cloud kept in a device buffer between the stages (the pf_*_device
+    calls, both handles on one stream)."""
     exe = os.path.join(ROOT, "driver", "step_loop")
     assert os.path.exists(exe), "driver/step_loop is not built (python -c 'import __graft_entry__ as g; g.build()')"
     g = np.load(os.path.join(golden_dir, "frames.npz"))
@@ -34,8 +37,9 @@ def test_cpp_driver_replays_the_reference_run(golden_dir, tmp_path):
         fp.write(np.ascontiguousarray(g["seed_vote"]).astype("<u4").tobytes())
         fp.write(np.ascontiguousarray(g["seed_rays"]).astype("<u4").tobytes())
         fp.write(np.ascontiguousarray(g["step_seed"]).astype("<u4").tobytes())
-    out = subprocess.run([exe, "replay", str(path)], capture_output=True, text=True, timeout=110)
+    out = subprocess.run([exe, mode, str(path)], capture_output=True, text=True, timeout=110)
     assert out.returncode == 0, out.stderr[-500:]
+    assert "callback(): 48 frames" in out.stderr
     frames, steps = {}, {}
     for line in out.stdout.splitlines():
         t = line.split()

@@ -189,6 +189,12 @@ struct pf_handle {
     double* h_u = nullptr;                         // pinned [2][Pg]
     double* d_u_map = nullptr;                     // the same memory as the device sees it
     int u_src = -1;                                // slot of h_u that holds the current set, -1: `u` does
+    // from PF_U_PREFETCH_MIN particles on, a fresh set goes to the device on a stream of its own while the step's
+    // earlier kernels still run, instead of the search reading it through the mapping (8 B per particle over PCIe
+    // inside the kernel: 160 us at a million particles)
+    double* u_pre = nullptr;                       // device [2][Pg]
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t u_event[2] = {nullptr, nullptr};
     unsigned long long rs_issued = 0, rs_done = 0; // resamples enqueued / results handed out
     unsigned long long* counters = nullptr;   // [3]
     PfResampleScratch rs{};            // block-level scratch of K3/K4
@@ -269,6 +275,10 @@ int fail(pf_handle* h, int code, const char* fmt, ...) {
     return code;
 }
 
+// particles (all ranks') from which fresh thresholds are copied ahead on their own stream. (One rank of eight, rehearsed: a
+// million particles 1.35 -> 1.24 ms per step; at 80 k, where the host is barely ahead of a 0.1 ms step, the copy and its
+// event came out slower than the search reading through the mapping, 0.125 against 0.108 ms.)
+#define PF_U_PREFETCH_MIN 262144
 #define HIP_TRY(h, expr)                                                                    \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
@@ -631,6 +641,9 @@ void pf_destroy(pf_handle* h) {
     for (hipEvent_t e : h->rs_event) if (e) (void)hipEventDestroy(e);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->h_u) (void)hipHostFree(h->h_u);
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    for (hipEvent_t e : h->u_event) if (e) (void)hipEventDestroy(e);
+    if (h->u_pre) (void)hipFree(h->u_pre);
     for (Stage* s : {&h->st_pose, &h->st_beams, &h->st_weights, &h->st_scan}) s->release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -775,6 +788,12 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     CREATE_TRY(hipHostGetDevicePointer((void**)&h->d_result, h->h_result, 0));
     CREATE_TRY(hipHostMalloc((void**)&h->h_u, 2 * sizeof(double) * Pg, hipHostMallocMapped));
     CREATE_TRY(hipHostGetDevicePointer((void**)&h->d_u_map, h->h_u, 0));
+    // SLAM_PF_U_PREFETCH=0: the search reads fresh thresholds through the mapping at every size (comparison)
+    if (Pg >= PF_U_PREFETCH_MIN && !(getenv("SLAM_PF_U_PREFETCH") && atoi(getenv("SLAM_PF_U_PREFETCH")) == 0)) {
+        CREATE_TRY(dalloc(&h->u_pre, 2 * Pg));
+        CREATE_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t& e : h->u_event) CREATE_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     CREATE_TRY(hipEventCreateWithFlags(&h->rs_event[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->rs_event[1], hipEventDisableTiming));
     {
@@ -1511,6 +1530,16 @@ int pf_resample_async(pf_handle* h, const double* u, const void* poses_global_de
         h->u_src = slot;
         h->have_u = true;
         u_dev = h->d_u_map + (size_t)slot * (size_t)h->Pg;
+        if (h->u_pre) {
+            // (the device slot is free for the same reason as the pinned one; the copy starts now, on its own stream,
+            // and this stream's search waits for it)
+            double* dst = h->u_pre + (size_t)slot * (size_t)h->Pg;
+            HIP_TRY(h, hipMemcpyAsync(dst, h->h_u + (size_t)slot * (size_t)h->Pg, sizeof(double) * (size_t)h->Pg,
+                                      hipMemcpyHostToDevice, h->copy_stream));
+            HIP_TRY(h, hipEventRecord(h->u_event[slot], h->copy_stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, h->u_event[slot], 0));
+            u_dev = dst;
+        }
     } else if (h->u_src >= 0) {
         HIP_TRY(h, hipMemcpyAsync(h->u, h->h_u + (size_t)h->u_src * (size_t)h->Pg, sizeof(double) * (size_t)h->Pg,
                                   hipMemcpyHostToDevice, h->stream));

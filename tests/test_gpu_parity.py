@@ -349,6 +349,48 @@ def test_boundary_draws_at_large_counts_match_the_sequential_loop(P):
         h.close()
 
 
+def test_fresh_thresholds_copied_ahead_at_large_counts(monkeypatch):
+    """From 262 144 particles on pf_resample sends a fresh threshold set to the device on a stream of its own (two
+    slots in turn) instead of letting the search read it through the host mapping: four resamples in a row, each with
+    its own weights and thresholds, the second and third without waiting for the one before (pf_resample_async, two
+    outstanding), against a handle created with SLAM_PF_U_PREFETCH=0 that reads through the mapping. (The oracle's
+    loop is quadratic in the particle count: test_boundary_draws_at_large_counts...[300000] above holds one resample
+    through the copied-ahead path against it.)"""
+    P, M, dims = 270000, 16, (32, 32, 32)
+    sc = synth.scene(dims, P, M, seed=4)
+    rng = np.random.default_rng(77)
+    ws = [rng.random(P) + 1e-3 for _ in range(4)]
+    ws = [w / w.sum() for w in ws]
+    us = [capi.draw_uniform(20 + k, P) for k in range(4)]
+
+    def run(prefetch):
+        monkeypatch.setenv("SLAM_PF_U_PREFETCH", "1" if prefetch else "0")
+        h = capi.Handle(_shared_cfg(P, dims, order_mode=capi.PF_ORDER_FAST))
+        try:
+            h.write_map(0, sc["grid"]); h.predict(sc["x"], sc["y"], sc["z"], sc["yaw"])
+            h.set_beams(*sc["beams"])
+            out = []
+            h.set_weights(ws[0])
+            out.append(h.resample(us[0])[:3])
+            for k in (1, 2):                              # two in flight: both slots of the threshold buffers in use
+                h.set_weights(ws[k])
+                h.resample_async(us[k], want_slots=True)
+            res = [h.resample_result() for _ in (1, 2)]
+            h.synchronize()
+            out += [r[:3] for r in res]
+            h.set_weights(ws[3])
+            out.append(h.resample(us[3])[:3])
+            return out
+        finally:
+            h.close()
+
+    got, want = run(True), run(False)
+    for k in range(4):
+        assert np.array_equal(got[k][0], want[k][0]) and got[k][1:] == want[k][1:], k
+        assert len(np.unique(got[k][0])) > P // 3
+    assert not np.array_equal(got[0][0], got[1][0])
+
+
 def test_draws_between_the_two_ambiguity_bands():
     """K4's band around a CDF boundary (FAST order): a draw inside the first, cheap band (k + 64 roundings of
     sums <= cdf[k]) is tested again with the sequential sum's error bounded through its partial sums block by

@@ -232,8 +232,11 @@ __device__ __forceinline__ void tile_phase(const PfTileG* __restrict__ cg, const
 
 // STATS (SLAM_PF_TILE_STATS=1, development aid): stats[0..3] += wave-beams by window load / the other ways / of groups
 // re-done in fp64; stats[4] += waves without coop_ok; stats[8..32): wave-beams by the wave's spread in cells
+#ifndef TILE_WG
+#define TILE_WG 256
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_measure_tile(
+__global__ __launch_bounds__(TILE_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_measure_tile(
         const double* __restrict__ sorted, int lanes, const int32_t* __restrict__ order,
         const uint8_t* __restrict__ shadow, const uint8_t* __restrict__ lin, PfSwz sw, const PfTileG* __restrict__ tab, const PfColG* __restrict__ cgz, int lzmin, int lzmax,
         PfGridParams gp, double lmax, int2* __restrict__ partial, unsigned long long* __restrict__ stats) {
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int4 ends = make_int4(row[0], row[1], row[2], row[3]), ends2 = make_int4(row[4], row[5], row[6], row[7]);
     const int gstart = row[PF_TILE_GROUP];
     const PfTileG* __restrict__ cg = tab + gridDim.y;
-    const int lane_id = blockIdx.x * 256 + threadIdx.x;
+    const int lane_id = blockIdx.x * TILE_WG + threadIdx.x;
     // a hole of the lane order (order[] = -1: the padding that starts every z class on a wave boundary)
     // stands in for the wave's first real lane, so that all 64 lanes take part in the window loads; a wave
     // of holes only has nothing to do
@@ -342,12 +345,12 @@ hipError_t pfk_measure_tile(hipStream_t st, const double* sorted, int lanes, con
                             const uint8_t* shadow, const uint8_t* lin, PfSwz sw, const PfTileG* cg, const PfColG* cgz,
                             int lzmin, int lzmax, int n_chunks, PfGridParams gp, double lmax, int2* partial) {
     static const bool want_stats = getenv("SLAM_PF_TILE_STATS") != nullptr;
-    const dim3 grid((lanes + 255) / 256, n_chunks);
+    const dim3 grid((lanes + TILE_WG - 1) / TILE_WG, n_chunks);
     if (want_stats) {
         unsigned long long* stats = nullptr;
         if (hipMalloc((void**)&stats, 256) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(stats, 0, 256, st);
-        hipLaunchKernelGGL(k_measure_tile<true>, grid, dim3(256), 0, st, sorted, lanes, order, shadow, lin, sw, cg, cgz, lzmin,
+        hipLaunchKernelGGL(k_measure_tile<true>, grid, dim3(TILE_WG), 0, st, sorted, lanes, order, shadow, lin, sw, cg, cgz, lzmin,
                            lzmax, gp, lmax, partial, stats);
         unsigned long long hs[32];
         (void)hipStreamSynchronize(st);
@@ -360,7 +363,7 @@ hipError_t pfk_measure_tile(hipStream_t st, const double* sorted, int lanes, con
         fprintf(stderr, "\n");
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_measure_tile<false>, grid, dim3(256), 0, st, sorted, lanes, order, shadow, lin, sw, cg, cgz, lzmin,
+    hipLaunchKernelGGL(k_measure_tile<false>, grid, dim3(TILE_WG), 0, st, sorted, lanes, order, shadow, lin, sw, cg, cgz, lzmin,
                        lzmax, gp, lmax, partial, (unsigned long long*)nullptr);
     return hipGetLastError();
 }

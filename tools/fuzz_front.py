@@ -180,7 +180,7 @@ def one_readout(rng, why):
 
 def one_local_update(rng, why):
     dims = tuple(int(v) for v in rng.integers(20, 150, 3))
-    n = int(rng.choice([1, 5, 64, 500, 3000])); r = int(rng.choice([0, 1, 100, 2400]))
+    n = int(rng.choice([1, 5, 64, 500, 3000])); r = int(rng.choice([0, 1, 100, 2400, 20000]))
     res = pick_res(rng)
     pos = snap(rng, np.array(dims) * res * rng.uniform(0.2, 0.8, 3), 0.3)
     zyx = np.array([rng.uniform(-3.2, 3.2), rng.normal(0, 0.03), rng.normal(0, 0.03)])

@@ -77,6 +77,15 @@ def one_vote(rng, why):
         note("votes"); note("votes with a winner", wbest >= 0); note("vote counts", int(want.sum()))
         if not (np.array_equal(got, want) and gbest == wbest):
             why.append(f"vote dims={dims} n={n} res={res} {kw}: {int((got != want).sum())} sums differ, best {gbest}/{wbest}")
+        if n:                                                  # the same points as rows pick[] of a larger cloud on the device
+            big = rng.normal(0, 2, (n + int(rng.integers(0, 50)), 3))
+            pick = rng.permutation(len(big))[:n].astype(np.int32)
+            big[pick] = pts
+            dev = torch.tensor(big.reshape(-1), device="cuda")
+            got2, gbest2 = h.scan_vote_device(dev.data_ptr(), len(big), pick, pos, zyx, **kw)
+            note("votes on a device cloud")
+            if not (np.array_equal(got2, want) and gbest2 == wbest):
+                why.append(f"vote_device dims={dims} n={n} {kw}: {int((got2 != want).sum())} sums differ")
         if n <= 4096 and kw["n_yaw"] <= 16 and kw["n_t"] <= 8:
             g = torch.tensor(grid.reshape(-1), device="cuda"); p = torch.tensor(np.ascontiguousarray(pts).reshape(-1), device="cuda")
             s = torch.zeros(kw["n_yaw"] * kw["n_t"] ** 3, dtype=torch.int32, device="cuda")
@@ -116,7 +125,12 @@ def one_ring(rng, why):
             if not np.array_equal(h.read_map(0).reshape(dims), grid):
                 why.append(f"ring dims={dims} cap={cap} slots={n_slots}: grid after paint, frame {t}"); return
             try:
-                gf, gpos = h.ring_update(cloud, pos, zyx)
+                if n and rng.random() < 0.5:                       # the cloud read where it is on the device
+                    dev = torch.tensor(np.ascontiguousarray(cloud).reshape(-1), device="cuda")
+                    gf, gpos = h.ring_update_device(dev.data_ptr(), n, pos, zyx)
+                    note("ring frames from a device cloud")
+                else:
+                    gf, gpos = h.ring_update(cloud, pos, zyx)
             except capi.PfError as e:
                 if n > cap:                                        # the library refuses what the reference would overrun
                     continue
@@ -154,6 +168,12 @@ def one_depth(rng, why):
         note("depth images"); note("cloud points", len(want))
         if not (got.shape == want.shape and np.array_equal(got, want)):
             why.append(f"depth {width}x{height} pool {pool} focal {focal}: {got.shape} vs {want.shape}")
+        cap = (width // pool) * (height // pool)
+        dev = torch.full((3 * cap + 3,), -7.0, dtype=torch.float64, device="cuda")
+        n2 = h.depth_to_cloud_device(raw, width, height, dev.data_ptr(), cap, pool, focal)
+        back = dev.cpu().numpy()
+        if not (n2 == len(want) and np.array_equal(back[:3 * n2].reshape(-1, 3), want) and np.all(back[3 * cap:] == -7.0)):
+            why.append(f"depth_device {width}x{height} pool {pool}: {n2} vs {len(want)}")
     finally:
         h.close()
 
@@ -198,7 +218,12 @@ def one_local_update(rng, why):
     h = capi.Handle(capi.default_config(n_particles=1, grid_x=8, grid_y=8, grid_z=8, local_x=dims[0], local_y=dims[1], local_z=dims[2],
                                         max_beams=16, max_points=max(n, r, 1), resolution=res))
     try:
-        h.write_local_map(grid); h.set_scan(pts, ridx)
+        h.write_local_map(grid)
+        if rng.random() < 0.5:
+            dev = torch.tensor(np.ascontiguousarray(pts).reshape(-1), device="cuda")
+            h.set_scan_device(dev.data_ptr(), n, ridx); note("local updates from a device cloud")
+        else:
+            h.set_scan(pts, ridx)
         h.update_map(capi.PF_GRID_LOCAL, capi.UpdateParams(*prm, mr), pos, zyx)
         got = h.read_local_map().reshape(dims)
         note("local updates"); note("local cells changed", int((want != grid).sum()))
